@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference).
+
+This script only runs in the build container (the reference never travels to the GPU box);
+its outputs under tests/golden/*.npz are plain data: inputs and expected outputs.
+
+The reference's Python files are imported unmodified.  Four modules it imports are not
+installed in this image (gym, visilibity, ray, mpi4py).  They are replaced by semantics-free
+placeholders created in a temp directory (never committed):
+
+  * gym        -- Env base class, spaces.Box/Discrete, registration.register, seeding names
+  * ray        -- empty module (imported by ppo.py, never used)
+  * mpi4py.MPI -- 1-rank communicator (Allreduce == copy); the reference's multi-agent
+                  entry point hard-disables MPI anyway (main.py:457-461)
+  * visilibity -- ONLY valid for obstruction_count == 0: the world is the convex outer
+                  wall, so Environment.shortest_path(a, b).length() IS the Euclidean
+                  distance; every obstacle-dependent call raises.  Obstacle-dependent
+                  quantities therefore stay "parity unpinned" (SURVEY.md section 8c).
+
+What is captured (SURVEY.md section 8c "Golden vectors"):
+  env_*.npz   transitions of RadSearch.step/reset with every RNG draw recorded
+  gae.npz     PPOBuffer.GAE_advantage_and_rewardsToGO + get() advantage normalisation
+  ff_core.npz FF_core.ActorCritic forward (weights + inputs + outputs)
+  welford.npz StatisticStandardization traces
+  round2.npz  Python round(x, 2) on the env's reward expressions
+"""
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_placeholders() -> str:
+    d = tempfile.mkdtemp(prefix="rs_placeholders_")
+
+    def w(rel, src):
+        p = os.path.join(d, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(textwrap.dedent(src))
+
+    w("gym/__init__.py", """
+        from . import spaces, envs, utils
+        class Env:
+            pass
+        def make(*a, **k):
+            raise NotImplementedError
+    """)
+    w("gym/spaces.py", """
+        class Box:
+            def __init__(self, low, high, shape=None, dtype=None):
+                self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+        class Discrete:
+            def __init__(self, n):
+                self.n = n
+    """)
+    w("gym/envs/__init__.py", "from . import registration\n")
+    w("gym/envs/registration.py", "def register(*a, **k):\n    pass\n")
+    w("gym/utils/__init__.py", "from . import seeding\n")
+    w("gym/utils/seeding.py", """
+        def _int_list_from_bigint(*a, **k):
+            raise NotImplementedError
+        def hash_seed(*a, **k):
+            raise NotImplementedError
+    """)
+    w("ray/__init__.py", "")
+    w("mpi4py/__init__.py", "from . import MPI\n")
+    w("mpi4py/MPI.py", """
+        SUM = "sum"; MIN = "min"; MAX = "max"
+        class _Comm:
+            def Get_rank(self): return 0
+            def Get_size(self): return 1
+            def Allreduce(self, x, buff, op=None):
+                buff[...] = x
+            def Bcast(self, x, root=0):
+                pass
+        COMM_WORLD = _Comm()
+    """)
+    w("visilibity.py", """
+        # Obstacle-free placeholder: the only polygon is the convex outer wall.
+        import math
+        class Point:
+            def __init__(self, x=0.0, y=0.0):
+                self._x, self._y = x, y
+            def x(self): return self._x
+            def y(self): return self._y
+            def _in(self, *a):
+                raise NotImplementedError("obstacle geometry is not available in the placeholder")
+        class Polygon:
+            def __init__(self, pts): self.pts = list(pts)
+            def bbox(self): raise NotImplementedError
+        class Line_Segment:
+            def __init__(self, a, b): self.a, self.b = a, b
+            def first(self): return self.a
+            def second(self): return self.b
+        class _Polyline:
+            def __init__(self, l): self._l = l
+            def length(self): return self._l
+        class Environment:
+            def __init__(self, polys):
+                assert len(polys) == 1, "placeholder supports obstruction_count == 0 only"
+            def is_valid(self, eps): return True
+            def shortest_path(self, a, b, graph, eps):
+                return _Polyline(math.sqrt(float((a.x() - b.x()) ** 2) + float((a.y() - b.y()) ** 2)))
+        class Visibility_Graph:
+            def __init__(self, env, eps): pass
+        def boundary_distance(*a): raise NotImplementedError
+        def intersect(*a): raise NotImplementedError
+        def distance(*a): raise NotImplementedError
+    """)
+    sys.path.insert(0, d)
+    return d
+
+
+class RecordingGenerator:
+    """Wraps numpy.random.Generator and logs every draw the env makes."""
+
+    def __init__(self, seed):
+        self._g = np.random.default_rng(seed)
+        self.log = []  # (kind, arg0, arg1, values...)
+
+    def integers(self, low, high=None, size=None, **kw):
+        v = self._g.integers(low, high, size=size, **kw)
+        vals = np.atleast_1d(np.asarray(v)).astype(np.int64).tolist()
+        self.log.append(("integers", float(low), float(high), vals))
+        return v
+
+    def poisson(self, lam=1.0, size=None):
+        v = self._g.poisson(lam, size)
+        self.log.append(("poisson", float(lam), 0.0, [int(v)]))
+        return v
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        v = self._g.normal(loc, scale, size)
+        self.log.append(("normal", float(loc), float(scale), np.atleast_1d(v).tolist()))
+        return v
+
+
+def _snapshot(env, A):
+    ag = [env.agents[i] for i in range(A)]
+    return dict(
+        det=[[float(a.det_coords[0]), float(a.det_coords[1])] for a in ag],
+        sp=[float(a.sp_dist) for a in ag],
+        euc=[float(a.euc_dist) for a in ag],
+        prev=[float(a.prev_det_dist) for a in ag],
+        oob=[bool(a.out_of_bounds) for a in ag],
+        oobc=[int(a.out_of_bounds_count) for a in ag],
+        coll=[bool(a.collision) for a in ag],
+        blocked=[bool(a.obstacle_blocking) for a in ag],
+        inter=[bool(a.intersect) for a in ag],
+        done=bool(env.done),
+        iter_count=int(env.iter_count),
+    )
+
+
+def _greedy_action(env, aid):
+    """Scripted policy helper: head for the source (forces the terminal branch)."""
+    from gym_rad_search.envs import rad_search_env as R
+    a = env.agents[aid]
+    best, bd = 8, None
+    for act in range(8):
+        st = R.get_step(act)
+        d = (a.det_coords[0] + st[0] - env.src_coords[0]) ** 2 + (a.det_coords[1] + st[1] - env.src_coords[1]) ** 2
+        if bd is None or d < bd:
+            best, bd = act, d
+    return best
+
+
+def gen_env_scenarios():
+    from gym_rad_search.envs.rad_search_env import RadSearch, get_step
+    # E1 action table
+    table = np.array([get_step(a) for a in range(9)], dtype=np.float64)
+    np.savez(os.path.join(OUT, "action_table.npz"), table=table)
+
+    for seed in (0, 1, 2, 289714752):
+        for A in (1, 2, 4):
+            for enforce in (True, False):
+                rec = RecordingGenerator(seed)
+                env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0,
+                                enforce_grid_boundaries=enforce)
+                rows = []   # one per event (reset or step)
+                script = np.random.default_rng(1000 + seed % 97 + A)
+
+                def record(kind, actions, ret, log_start):
+                    obs, rew, done, info = ret
+                    snap = _snapshot(env, A)
+                    draws = rec.log[log_start:]
+                    rows.append(dict(
+                        kind=kind, actions=actions,
+                        obs=[np.asarray(obs[i], dtype=np.float64).tolist() for i in range(A)],
+                        reward=[float(rew["individual_reward"][i]) for i in range(A)],
+                        team=float("nan") if rew["team_reward"] is None else float(rew["team_reward"]),
+                        done_ret=[bool(done[i]) for i in range(A)],
+                        info_oob=[bool(info[i]["out_of_bounds"]) for i in range(A)],
+                        info_oobc=[int(info[i]["out_of_bounds_count"]) for i in range(A)],
+                        info_blocked=[bool(info[i]["blocked"]) for i in range(A)],
+                        src=[float(env.src_coords[0]), float(env.src_coords[1])],
+                        intensity=int(env.intensity), bkg=int(env.bkg_intensity),
+                        draws=draws, **snap))
+
+                # the constructor already performed one reset; redo it under recording
+                ls = len(rec.log)
+                env.epoch_end = True
+                ret = env.reset()
+                record("reset", [8] * A, ret, ls)
+                steps_in_ep = 0
+                phase = 0
+                for t in range(260):
+                    # phases: random walk / wall seeking / greedy approach / idle+collisions
+                    phase = (t // 40) % 5
+                    if phase == 0:
+                        acts = [int(script.integers(0, 9)) for _ in range(A)]
+                    elif phase == 1:
+                        acts = [[0, 6, 7, 5][i % 4] for i in range(A)]       # run into left/bottom walls
+                    elif phase == 2:
+                        acts = [_greedy_action(env, i) for i in range(A)]    # terminal approach
+                    elif phase == 3:
+                        acts = [[4, 2, 3, 1][i % 4] for i in range(A)]       # run into right/top walls
+                    else:
+                        acts = [8 if (t + i) % 3 == 0 else int(script.integers(0, 8)) for i in range(A)]
+                    ls = len(rec.log)
+                    if A == 1 and t % 7 == 3:
+                        # single-int calling convention (rad_search_env.py:620-623,676-690)
+                        ret = env.step(acts[0] if acts[0] != 8 else -1)
+                    else:
+                        ret = env.step({i: acts[i] for i in range(A)})
+                    record("step", acts, ret, ls)
+                    steps_in_ep += 1
+                    if env.done or steps_in_ep == 30:
+                        ls = len(rec.log)
+                        if t % 2 == 0:
+                            env.epoch_end = True
+                        ret = env.reset()
+                        record("reset", [8] * A, ret, ls)
+                        steps_in_ep = 0
+                _save_env_rows(os.path.join(OUT, f"env_s{seed}_a{A}_e{int(enforce)}.npz"), rows, A,
+                               dict(seed=seed, A=A, enforce=int(enforce)))
+
+
+def _save_env_rows(path, rows, A, meta):
+    n = len(rows)
+    f8 = lambda k: np.array([r[k] for r in rows], dtype=np.float64)
+    i8 = lambda k: np.array([r[k] for r in rows], dtype=np.int64)
+    # flatten the draw log: (event, kind, arg0, arg1, value)
+    kinds = {"integers": 0, "poisson": 1, "normal": 2}
+    dl = []
+    for e, r in enumerate(rows):
+        for (k, a0, a1, vals) in r["draws"]:
+            for v in vals:
+                dl.append((e, kinds[k], a0, a1, float(v)))
+    np.savez_compressed(
+        path,
+        meta=np.array([meta["seed"], meta["A"], meta["enforce"]], dtype=np.int64),
+        is_reset=np.array([r["kind"] == "reset" for r in rows], dtype=np.int8),
+        actions=i8("actions"), obs=f8("obs"), reward=f8("reward"), team=f8("team"),
+        done_ret=i8("done_ret"), info_oob=i8("info_oob"), info_oobc=i8("info_oobc"),
+        info_blocked=i8("info_blocked"), src=f8("src"), intensity=i8("intensity"), bkg=i8("bkg"),
+        det=f8("det"), sp=f8("sp"), euc=f8("euc"), prev=f8("prev"), oob=i8("oob"), oobc=i8("oobc"),
+        coll=i8("coll"), blocked=i8("blocked"), inter=i8("inter"), done=i8("done"),
+        iter_count=i8("iter_count"),
+        draws=np.array(dl, dtype=np.float64).reshape(-1, 5),
+    )
+    print("wrote", path, n, "events", len(dl), "draws")
+
+
+def gen_gae():
+    sys.path.insert(0, os.path.join(REF))
+    from algos.multiagent.ppo import PPOBuffer, discount_cumsum  # noqa
+    rng = np.random.default_rng(7)
+    cases = []
+    # known-answer vector of the reference's own test (unit_tests/test_PPO.py:263-270)
+    T = 480
+    buf = PPOBuffer(observation_dimension=11, max_size=T, max_episode_length=120, number_agents=1)
+    rew = (rng.integers(-70, 11, size=T) / 100.0).astype(np.float64)
+    val = rng.normal(size=T).astype(np.float32)
+    logp = rng.normal(size=T).astype(np.float32)
+    cut = np.zeros(T, dtype=np.int8)       # 1 = trajectory ends after this step
+    term = np.zeros(T, dtype=np.int8)      # 1 = terminal (last_val = 0), else bootstrap
+    last_vals = np.zeros(T, dtype=np.float64)
+    ep_lens = []
+    start = 0
+    t = 0
+    while t < T:
+        length = int(rng.integers(3, 121))
+        end = min(t + length, T)
+        is_term = bool(rng.integers(0, 2)) and end < T
+        for s in range(t, end):
+            buf.store(obs=np.zeros(11, np.float32), act=1, rew=float(rew[s]), val=float(val[s]),
+                      logp=float(logp[s]), src=np.zeros(2, np.float32), full_observation={},
+                      heatmap_stacks=None, terminal=(s == end - 1))
+        lv = 0.0 if is_term else float(np.float32(rng.normal()))
+        buf.GAE_advantage_and_rewardsToGO(lv)
+        cut[end - 1] = 1
+        term[end - 1] = int(is_term)
+        last_vals[end - 1] = lv
+        if is_term or (end - t) == 120 or end < T:
+            buf.store_episode_length(end - t)
+            ep_lens.append(end - t)
+        t = end
+    adv_raw = buf.adv_buf.copy()
+    ret = buf.ret_buf.copy()
+    data = buf.get()
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), rew=rew, val=val, cut=cut, term=term,
+                        last_val=last_vals, adv_raw=adv_raw, ret=ret,
+                        adv_norm=data["adv"].numpy(), gamma=0.99, lam=0.90,
+                        ep_lens=np.array(ep_lens, dtype=np.int64),
+                        n_ep_form=len(data["ep_form"]))
+    print("wrote gae.npz; episodes", len(ep_lens), "ep_form", len(data["ep_form"]))
+
+
+def gen_ff_core():
+    import torch
+    from algos.multiagent.NeuralNetworkCores.FF_core import ActorCritic
+    torch.manual_seed(11)
+    ac = ActorCritic(state_dim=11, action_dim=8, has_continuous_action_space=False, action_std_init=0.6)
+    x = torch.rand(64, 11)
+    x[:, 0] = torch.randint(0, 5000, (64,)).float()      # raw counts, as the env emits them
+    with torch.no_grad():
+        probs = ac.actor(x)
+        values = ac.critic(x)
+        act = torch.arange(64) % 8
+        logp, v2, ent = ac.evaluate(x, act)
+    sd = {k: v.numpy() for k, v in ac.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "ff_core.npz"), x=x.numpy(), probs=probs.numpy(),
+                        values=values.numpy(), act=act.numpy(), logp=logp.numpy(), ent=ent.numpy(),
+                        **{"sd_" + k: v for k, v in sd.items()})
+    print("wrote ff_core.npz", list(sd))
+
+
+def gen_welford():
+    from algos.multiagent.NeuralNetworkCores.RADTEAM_core import StatisticStandardization
+    rng = np.random.default_rng(3)
+    xs = rng.poisson(rng.uniform(20, 5000, size=200)).astype(np.float64)
+    st = StatisticStandardization()
+    out = []
+    for x in xs:
+        st.update(x)
+        out.append(st.standardize(x))
+    np.savez_compressed(os.path.join(OUT, "welford.npz"), x=xs, z=np.array(out, dtype=np.float64))
+    print("wrote welford.npz")
+
+
+def gen_round2():
+    rng = np.random.default_rng(5)
+    sp = np.concatenate([rng.uniform(0, 4000, 200000), rng.integers(0, 400000, 200000) / 100.0,
+                         np.arange(0, 4000, 0.5)])
+    a = np.array([round(-0.5 * s / 2000.0, 2) for s in sp])
+    b = np.array([round(-1.0 * s / 2000.0, 2) for s in sp])
+    # keep the fixture small: sample 20k
+    idx = rng.choice(len(sp), 20000, replace=False)
+    np.savez_compressed(os.path.join(OUT, "round2.npz"), sp=sp[idx], half=a[idx], full=b[idx])
+    print("wrote round2.npz")
+
+
+if __name__ == "__main__":
+    _install_placeholders()
+    sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
+    sys.path.insert(0, REF)
+    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2"]
+    if "env" in which:
+        gen_env_scenarios()
+    if "gae" in which:
+        gen_gae()
+    if "ff" in which:
+        gen_ff_core()
+    if "welford" in which:
+        gen_welford()
+    if "round2" in which:
+        gen_round2()
