@@ -1,0 +1,132 @@
+/*
+ * radsearch.h -- C ABI of the MI355X-native radiation-search PPO hot path (librs_hip.so).
+ *
+ * The reference (bentotten/radiation_ppo) has no plugin/FFI interface: its boundary is two Python
+ * call surfaces.  This ABI sits directly behind them; every entry point names the reference
+ * interface it replaces (paths relative to the reference root):
+ *
+ *   rs_step      <- RadSearch.step            gym_rad_search/gym_rad_search/envs/rad_search_env.py:443-728
+ *   rs_reset     <- RadSearch.reset           rad_search_env.py:730-797 (+ create_obs :948-1011,
+ *                                             sample_source_loc_pos :1013-1131)
+ *   rs_set_epoch_end <- `env.epoch_end = True` algos/multiagent/train.py:482-484
+ *   rs_gae       <- PPOBuffer.GAE_advantage_and_rewardsToGO   algos/multiagent/ppo.py:391-423
+ *                   (discount_cumsum ppo.py:62-85), one call for the whole [T, N*A] buffer
+ *   rs_rollout   <- the collector loop        algos/multiagent/train.py:332-548 with the
+ *                   FF_core.ActorCritic policy (NeuralNetworkCores/FF_core.py:42-129)
+ *   rs_ppo_loss_grad <- AgentPPO.update_rada2c loss/backward  ppo.py:1206-1256
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch types, no exceptions; return 0 = RS_OK.
+ *   - every pointer marked "device" is HBM owned by the CALLER (PyTorch tensors in the Python host);
+ *     the library borrows it for the duration of the call's stream-ordered work.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises.
+ *   - no allocation after rs_create; one handle per device; a handle is not thread-safe.
+ *   - environments are independent: a multi-GPU job gives each rank its own handle with
+ *     env_id_base = first global env id of the rank (results do not depend on the sharding).
+ */
+#ifndef RADSEARCH_H
+#define RADSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ABI_VERSION 1
+#define RS_OBS_DIM 11      /* [measurement, x/scale, y/scale, 8 range sensors]  rad_search_env.py:589-593 */
+#define RS_NUM_ACTIONS 9   /* 0..7 directions, 8 idle                           rad_search_env.py:55-68  */
+#define RS_MAX_AGENTS 8
+#define RS_MAX_OBS 7       /* obstruction_count in {-1,0..7}                    rad_search_env.py:315,327 */
+
+typedef void* rs_stream_t; /* hipStream_t */
+typedef struct rs_handle rs_handle;
+
+enum {
+    RS_OK = 0,
+    RS_ERR_INVALID_ARG = 1,
+    RS_ERR_HIP = 2,
+    RS_ERR_WORKSPACE = 3,
+    RS_ERR_UNSUPPORTED = 4
+};
+
+/* per-env error bits accumulated on the device (conditions on which the reference raises) */
+enum {
+    RS_ENVERR_ZERO_DIST = 1,   /* detector on the source: intensity / 0 (rad_search_env.py:501)            */
+    RS_ENVERR_IDLE_STALL = 2,  /* idle action stalled without collision (ValueError, :544-547, :562-565)  */
+    RS_ENVERR_CORRECT_CAP = 4, /* correct_coords loop (:1278) hit the iteration cap                       */
+    RS_ENVERR_BAD_ACTION = 8   /* action outside 0..8 / -1 (assert, :616-627)                             */
+};
+
+typedef struct rs_config {
+    int32_t num_envs;                /* N: envs owned by this handle                                   */
+    int32_t num_agents;              /* A: 1..RS_MAX_AGENTS (number_agents, rad_search_env.py:354)     */
+    int32_t obstruction_count;       /* -1 => U{1..5} per epoch, 0 none, 1..7 (rad_search_env.py:327)  */
+    int32_t enforce_grid_boundaries; /* rad_search_env.py:328                                          */
+    int32_t bbox[4];                 /* x0,y0,x1,y1 in cm (default 0,0,2700,2700; :320-324)            */
+    int32_t observation_area[2];     /* (200,500) (:325)                                               */
+    int32_t falloff;                 /* 0 = as written in the reference, I/r (:501); 1 = I/r^2         */
+    int32_t geom_group_size;         /* envs sharing one obstacle layout; 1 = reference-faithful       */
+    uint32_t seed;                   /* Philox key word 0                                              */
+    uint32_t env_id_base;            /* global id of local env 0 (Philox key word 1 = base + n)        */
+} rs_config;
+
+/* optional per-agent info outputs of rs_step / rs_reset (any pointer may be NULL); all device, [N,A] */
+typedef struct rs_info {
+    uint8_t* out_of_bounds;       /* info["out_of_bounds"]        rad_search_env.py:607-612 */
+    int32_t* out_of_bounds_count; /* info["out_of_bounds_count"]                            */
+    uint8_t* blocked;             /* info["blocked"] (sticky per episode)                   */
+    uint8_t* collision;           /* Agent.collision (:268)                                 */
+} rs_info;
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+const char* rs_strerror(int code);
+int rs_abi_version(void);
+
+/* bytes of device workspace a handle needs for `cfg` (0 on invalid cfg) */
+size_t rs_state_bytes(const rs_config* cfg);
+
+/* workspace: device memory of >= rs_state_bytes(cfg) bytes, 256-byte aligned, owned by the caller
+ * and kept alive until rs_destroy.  Zero-fills it on `stream`; every env starts with epoch_end set
+ * (rad_search_env.py:421) and must be rs_reset before the first rs_step. */
+int rs_create(const rs_config* cfg, void* workspace, size_t workspace_bytes, rs_stream_t stream, rs_handle** out);
+void rs_destroy(rs_handle* h);
+
+/* introspection for tests/adapters: device pointer + shape of one SoA state field.
+ * names: "src_x","src_y","intensity","bkg","iter_count","episode","tstep","err","done","epoch_end"
+ * ([N]); "num_obs" ([G]); "rect" ([28,G] int32: (obstacle*4 + {x0,y0,x1,y1}) major); "dsrc" ([28,N] f64);
+ * "x","y","oob_count" ([A,N] int32); "sp","prev" ([A,N] f64); "aflags" ([A,N] u8: bit0 blocked,
+ * bit1 intersect, bit2 out_of_bounds, bit3 collision).  elem: 1,4,8 bytes. */
+int rs_state_field(rs_handle* h, const char* name, void** dev_ptr, int32_t* elem_bytes, int32_t* rows, int32_t* cols);
+
+/* ---- environment ----------------------------------------------------------------------------- */
+/* `env.epoch_end = True` for every env: the next rs_reset of an env resamples its obstacle layout. */
+int rs_set_epoch_end(rs_handle* h, rs_stream_t stream);
+
+/* Reset the envs whose mask byte is non-zero (mask == NULL: all).  For those envs writes the initial
+ * observation (the reference's `step(None)`), reward, team reward, done and info rows; other rows are
+ * left untouched.  obs [N,A,11] f32, reward [N,A] f32, team [N] f32, done [N,A] u8 (any may be NULL). */
+int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float* team, uint8_t* done,
+             const rs_info* info, rs_stream_t stream);
+
+/* One lock-step of all N envs.  actions [N,A] int8 in 0..8 (-1 == idle 8).  Outputs as rs_reset.
+ * done[n,a] is the env-wide latch as seen when agent a returned (rad_search_env.py:509,613). */
+int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, float* team, uint8_t* done,
+            const rs_info* info, rs_stream_t stream);
+
+/* host copy of the OR of all per-env error bits (synchronises `stream`; debugging/adapters only) */
+int rs_error_flags(rs_handle* h, rs_stream_t stream, uint32_t* flags_out);
+
+/* ---- PPO buffer math ------------------------------------------------------------------------ */
+/* GAE(lambda) advantages and rewards-to-go for a whole rollout buffer, time-major [T, M] (M = N*A
+ * columns, one trajectory stream per column).  cut[t,m] != 0: the trajectory of column m ends after
+ * step t and last_val[t,m] is its bootstrap value (V(s_T) on timeout / epoch cut, 0 on terminal,
+ * train.py:462-487).  Computed in float64 per column exactly as scipy.lfilter does, stored float32. */
+int rs_gae(const float* rew, const float* val, const uint8_t* cut, const float* last_val, float* adv, float* ret,
+           int32_t T, int32_t M, double gamma, double lam, rs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADSEARCH_H */

@@ -70,6 +70,7 @@ _M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 _MASK = 0xFFFFFFFF
 STREAM_RESET = 0
 STREAM_STEP = 1           # + agent id
+STREAM_GEOM = 64          # obstacle layouts shared by a group of envs (geom_group_size > 1)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -123,7 +124,8 @@ def poisson_from_uniforms(lam, next_uv):
             return int(k)
         if k < 0 or (us < 0.013 and v > us):
             continue
-        if (math.log(v) + math.log(invalpha) - math.log(a / (us * us) + b)) <= (-lam + k * loglam - math.lgamma(k + 1.0)):
+        logv = math.log(v) if v > 0.0 else -math.inf
+        if (logv + math.log(invalpha) - math.log(a / (us * us) + b)) <= (-lam + k * loglam - math.lgamma(k + 1.0)):
             return int(k)
 
 
@@ -156,6 +158,42 @@ class PhiloxDraws:
             o = philox4x32_10(i & _MASK, self.t, self.episode, STREAM_STEP + agent, self.k0, self.k1)
             return u53(o[0], o[1]), u53(o[2], o[3])
         return poisson_from_uniforms(lam, next_uv)
+
+
+class PhiloxGeomDraws:
+    """Draws for an obstacle layout shared by a group of envs: key = (seed, first env id of the
+    group), counter = (draw index, 0, geometry epoch, STREAM_GEOM)."""
+
+    def __init__(self, seed, first_env_id):
+        self.k0 = seed & _MASK
+        self.k1 = first_env_id & _MASK
+        self.epoch = 0
+        self.idx = 0
+
+    def begin(self, geom_epoch):
+        self.epoch = geom_epoch & _MASK
+        self.idx = 0
+
+    def integers(self, lo, hi):
+        o = philox4x32_10(self.idx & _MASK, 0, self.epoch, STREAM_GEOM, self.k0, self.k1)
+        self.idx += 1
+        x = (o[1] << 32) | o[0]
+        return lo + ((x * (hi - lo)) >> 64)
+
+
+def sample_layout(draws, obstruction_count, sa_x0=200, sa_y0=200, sa_x1=2200, sa_y1=2200, oa=(200, 500)):
+    """create_obs (:948-1011) + the num_obs draw (:745-750) as a free function (shared layouts)."""
+    num = draws.integers(1, 6) if obstruction_count == -1 else obstruction_count
+    rects = []
+    while len(rects) < num:
+        sx = draws.integers(sa_x0, int(sa_x1 * 0.9))
+        sy = draws.integers(sa_y0, int(sa_y1 * 0.9))
+        ex = draws.integers(oa[0], oa[1])
+        ey = draws.integers(oa[0], oa[1])
+        r = (sx, sy, sx + ex, sy + ey)
+        if not any(RadSearchOracle._rect_boundaries_touch(q, r) for q in rects):
+            rects.append(r)
+    return rects
 
 
 class ReplayDraws:
@@ -405,7 +443,8 @@ class OracleAgent:
 
 class RadSearchOracle:
     def __init__(self, draws, number_agents=1, obstruction_count=0, enforce_grid_boundaries=False,
-                 bbox=(0, 0, 2700, 2700), observation_area=(200, 500), falloff="reference"):
+                 bbox=(0, 0, 2700, 2700), observation_area=(200, 500), falloff="reference", layout_fn=None):
+        self.layout_fn = layout_fn      # callable() -> rects for shared layouts (geom_group_size > 1)
         self.rng = draws
         self.number_agents = number_agents
         self.obstruction_count = obstruction_count
@@ -540,6 +579,10 @@ class RadSearchOracle:
         self.iter_count = 0
         self.rng.begin_reset(self.episode)
         self.t = 0
+        if self.epoch_end and self.layout_fn is not None:
+            self.rects = list(self.layout_fn())
+            self.num_obs = len(self.rects)
+            self.epoch_end = False
         if self.epoch_end:
             if self.obstruction_count == -1:
                 self.num_obs = self.rng.integers(1, 6)

@@ -1,0 +1,83 @@
+"""ctypes binding of librs_hip.so (the C ABI in include/radsearch.h).
+
+torch is imported first on purpose: PyTorch-ROCm ships its own libamdhip64.so.7; loading it before
+our library makes the dynamic loader resolve our DT_NEEDED entry to the SAME runtime instance, so
+device pointers and streams created by torch are valid in our launches."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "librs_hip.so")
+
+RS_OBS_DIM = 11
+RS_MAX_AGENTS = 8
+RS_MAX_OBS = 7
+
+ENVERR_ZERO_DIST = 1
+ENVERR_IDLE_STALL = 2
+ENVERR_CORRECT_CAP = 4
+ENVERR_BAD_ACTION = 8
+
+
+class RsConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("obstruction_count", C.c_int32),
+        ("enforce_grid_boundaries", C.c_int32), ("bbox", C.c_int32 * 4), ("observation_area", C.c_int32 * 2),
+        ("falloff", C.c_int32), ("geom_group_size", C.c_int32), ("seed", C.c_uint32), ("env_id_base", C.c_uint32),
+    ]
+
+
+class RsInfo(C.Structure):
+    _fields_ = [("out_of_bounds", C.c_void_p), ("out_of_bounds_count", C.c_void_p), ("blocked", C.c_void_p),
+                ("collision", C.c_void_p)]
+
+
+# every symbol include/radsearch.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("rs_strerror", C.c_char_p, [C.c_int]),
+    ("rs_abi_version", C.c_int, []),
+    ("rs_state_bytes", C.c_size_t, [C.POINTER(RsConfig)]),
+    ("rs_create", C.c_int, [C.POINTER(RsConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("rs_destroy", None, [C.c_void_p]),
+    ("rs_state_field", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("rs_set_epoch_end", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rs_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.POINTER(RsInfo), C.c_void_p]),
+    ("rs_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.POINTER(RsInfo), C.c_void_p]),
+    ("rs_error_flags", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                         C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+]
+
+_lib = None
+
+
+def load():
+    """Load librs_hip.so (once).  Fails loudly: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `python radiation_ppo_amd/build.py`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rs_abi_version() != 1:
+        raise RuntimeError("librs_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().rs_strerror(code).decode()
+        raise RuntimeError(f"librs_hip {what}: {msg} (code {code})")

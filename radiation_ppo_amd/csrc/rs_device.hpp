@@ -1,0 +1,541 @@
+// rs_device.hpp -- device-side building blocks of the radiation-search env for gfx950 (CDNA4).
+//
+// One environment per wavefront lane.  All geometry is exact integer-lattice arithmetic (int32/int64);
+// distances, Poisson rates and rewards are float64 with FP contraction OFF (-ffp-contract=off) so the
+// results are the IEEE values the reference's Python floats produce.
+//
+// Reference behaviour restated here (paths relative to the reference root,
+// gym_rad_search/gym_rad_search/envs/rad_search_env.py): get_step :178-224, take_action :876-946,
+// agent_step :460-613, is_intersect :1133-1146, in_obstruction :1148-1170, obstruction_sensors
+// :1172-1261, correct_coords :1263-1306, create_obs :948-1011, sample_source_loc_pos :1013-1131.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RS_WAVE 64
+#define RS_OBS_DIM 11
+#define RS_MAX_AGENTS 8
+#define RS_MAX_OBS 7
+#define RS_MAX_VERT (4 * RS_MAX_OBS)
+#define RS_IDLE 8
+#define RS_ACT_NONE 9          // internal: the reference's step(None) during reset
+#define RS_CORRECT_CAP 4096
+
+#define RS_ENVERR_ZERO_DIST 1u
+#define RS_ENVERR_IDLE_STALL 2u
+#define RS_ENVERR_CORRECT_CAP 4u
+#define RS_ENVERR_BAD_ACTION 8u
+
+#define RS_AF_BLOCKED 1
+#define RS_AF_INTERSECT 2
+#define RS_AF_OOB 4
+#define RS_AF_COLLISION 8
+
+#define RS_STREAM_RESET 0u
+#define RS_STREAM_STEP 1u      // + agent id
+#define RS_STREAM_GEOM 64u
+
+// ---------------------------------------------------------------------------------------------
+// Kernel parameter block (passed by value as kernarg).  All arrays are SoA, env index fastest, so a
+// wave's 64 lanes read/write 64 consecutive elements of every field (coalesced 256-/512-byte rows).
+struct RsParams {
+    int N, A, G;                       // envs, agents, geometry groups (G = ceil(N / group))
+    int obstruction_count, enforce, falloff, group;
+    int bx0, by0, bx1, by1;            // bbox
+    int sa_x0, sa_y0, sa_x1, sa_y1;    // search area (rad_search_env.py:393-420)
+    int oa_lo, oa_hi;                  // observation_area
+    int obs_hi_x, obs_hi_y;            // int(search_area[2] * 0.9): exclusive bound of the obstacle seed
+    double max_dist, scale;
+    uint32_t seed, env_id_base;
+    // per env [N]
+    int *src_x, *src_y, *intensity, *bkg, *iter_count;
+    uint32_t *episode, *tstep, *err;
+    uint8_t *done, *epoch_end;
+    // per geometry group
+    int* num_obs;                      // [G]
+    int* rect;                         // [28][G]
+    uint32_t* geom_epoch;              // [G]
+    double* dsrc;                      // [28][N] geodesic distance source -> rectangle vertex
+    // per agent [A][N]
+    int *ax, *ay, *oobc;
+    double *sp, *prev;
+    uint8_t* aflags;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  key = (seed, global env id); counter = (draw, step, episode, stream)
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double u53(uint32_t lo, uint32_t hi) {
+    uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)v * (1.0 / 9007199254740992.0);
+}
+
+// sequential integer draws of one reset (or one geometry resample)
+struct RsDrawSeq {
+    uint32_t k0, k1, c2, c3, idx;
+    __device__ __forceinline__ int integers(int lo, int hi) {
+        u32x4 o = philox4x32_10(idx, 0u, c2, c3, k0, k1);
+        idx += 1;
+        uint64_t x = ((uint64_t)o.y << 32) | o.x;
+        return lo + (int)__umul64hi(x, (uint64_t)(uint32_t)(hi - lo));
+    }
+};
+
+// Poisson(lam): Hormann PTRS for lam >= 10 (what numpy's Generator.poisson does there), the
+// multiplication method below 10.  Uniform pair i of the draw comes from Philox counter word 0 = i.
+__device__ __forceinline__ int64_t rs_poisson(double lam, uint32_t t, uint32_t episode, uint32_t stream, uint32_t k0, uint32_t k1) {
+    if (lam == 0.0) return 0;
+    if (lam < 10.0) {
+        double enlam = exp(-lam);
+        int64_t x = 0;
+        double prod = 1.0;
+        for (uint32_t i = 0;; ++i) {
+            u32x4 o = philox4x32_10(i, t, episode, stream, k0, k1);
+            prod *= u53(o.x, o.y);
+            if (prod > enlam) x += 1; else return x;
+        }
+    }
+    double slam = sqrt(lam);
+    double loglam = log(lam);
+    double b = 0.931 + 2.53 * slam;
+    double a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (uint32_t i = 0;; ++i) {
+        u32x4 o = philox4x32_10(i, t, episode, stream, k0, k1);
+        double u = u53(o.x, o.y) - 0.5;
+        double v = u53(o.z, o.w);
+        double us = 0.5 - fabs(u);
+        if (!(us > 0.0)) continue;
+        double k = floor((2.0 * a / us + b) * u + lam + 0.43);
+        if (us >= 0.07 && v <= vr) return (int64_t)k;
+        if (k < 0.0 || (us < 0.013 && v > us)) continue;
+        double lhs = log(v) + log(invalpha) - log(a / (us * us) + b);
+        double rhs = -lam + k * loglam - lgamma(k + 1.0);
+        if (lhs <= rhs) return (int64_t)k;
+    }
+}
+
+// round(x, 2) of a Python float (rad_search_env.py:613): correctly rounded, ties-to-even on the EXACT
+// binary value.  x = m * 2^e exactly, so x*100 = (100 m) / 2^s is classified with integer arithmetic.
+__device__ __forceinline__ double rs_round2(double x) {
+    uint64_t bits = (uint64_t)__double_as_longlong(x);
+    int ex = (int)((bits >> 52) & 0x7ff);
+    if (ex == 0x7ff) return x;
+    double sgn = (bits >> 63) ? -1.0 : 1.0;
+    if (ex == 0) return sgn * 0.0;
+    uint64_t m = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+    int s = 1075 - ex;                 // x = m * 2^-s
+    if (s <= 0) return x;              // |x| >= 2^52: already an integer
+    if (m >= (1ull << 57)) return x;   // unreachable (m < 2^53)
+    uint64_t P = m * 100ull;           // < 2^60
+    if (s >= 61) return sgn * 0.0;     // |x*100| < 1/2
+    uint64_t q = P >> s;
+    uint64_t rem = P & ((1ull << s) - 1ull);
+    uint64_t half = 1ull << (s - 1);
+    if (rem > half || (rem == half && (q & 1ull))) q += 1;
+    return sgn * ((double)q / 100.0);
+}
+
+__device__ __forceinline__ bool rs_isclose_abs(double a, double b, double abs_tol) {   // math.isclose, rel_tol 1e-9
+    if (a == b) return true;
+    if (isinf(a) || isinf(b)) return false;
+    double diff = fabs(b - a);
+    return (diff <= fabs(1e-9 * b)) || (diff <= fabs(1e-9 * a)) || (diff <= abs_tol);
+}
+
+__device__ __forceinline__ double rs_dist_i(int ax, int ay, int bx, int by) {          // dist_p :125-136
+    double dx = (double)(ax - bx), dy = (double)(ay - by);
+    return sqrt(dx * dx + dy * dy);
+}
+
+__device__ __forceinline__ void rs_action_step(int a, int& dx, int& dy) {              // get_step :205-224
+    // 0:(-100,0) 1:(-71,71) 2:(0,100) 3:(71,71) 4:(100,0) 5:(71,-71) 6:(0,-100) 7:(-71,-71) 8:(0,0)
+    const int cx = (a == 8) ? 0 : ((a >= 3 && a <= 5) ? 1 : ((a == 2 || a == 6) ? 0 : -1));
+    const int cy = (a == 8) ? 0 : ((a >= 1 && a <= 3) ? 1 : ((a == 0 || a == 4) ? 0 : -1));
+    const int sz = (a & 1) ? 71 : 100;
+    dx = cx * sz; dy = cy * sz;
+}
+__device__ __forceinline__ void rs_dir_coeff(int a, int& cx, int& cy) {                // :186-202
+    cx = (a >= 3 && a <= 5) ? 1 : ((a == 2 || a == 6) ? 0 : -1);
+    cy = (a >= 1 && a <= 3) ? 1 : ((a == 0 || a == 4) ? 0 : -1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Obstacle layout staged in LDS.  per-lane layout: word (o*4+c) of lane l at r[(o*4+c)*64 + l]
+// (conflict-free: consecutive lanes -> consecutive banks); shared layout (a whole wave uses one
+// layout): r[o*4+c], every lane reads the same word (LDS broadcast).
+struct RsGeo {
+    const int* r;
+    int stride, off, n;     // n = number of obstacles
+    __device__ __forceinline__ int get(int o, int c) const { return r[(o * 4 + c) * stride + off]; }
+    __device__ __forceinline__ void rect(int o, int& x0, int& y0, int& x1, int& y1) const {
+        x0 = get(o, 0); y0 = get(o, 1); x1 = get(o, 2); y1 = get(o, 3);
+    }
+    // vertex order of create_obs (:975-983): (x0,y0) (x0,y1) (x1,y1) (x1,y0)
+    __device__ __forceinline__ void vertex(int v, int& vx, int& vy) const {
+        int o = v >> 2, c = v & 3;
+        vx = get(o, (c >= 2) ? 2 : 0);
+        vy = get(o, (c == 1 || c == 2) ? 3 : 1);
+    }
+};
+
+__device__ __forceinline__ bool rs_frac_lt(int n1, int d1, int n2, int d2) { return (int64_t)n1 * d2 < (int64_t)n2 * d1; }
+
+// closed segment p-q meets the OPEN interior of [x0,x1]x[y0,y1]?  (exact)
+__device__ __forceinline__ bool rs_seg_hits_open_rect(int px, int py, int qx, int qy, int x0, int y0, int x1, int y1) {
+    int dx = qx - px, dy = qy - py;
+    int ln = -1, ld = 1, un = 2, ud = 1;      // t in (-1, 2) to start: neutral bounds
+    bool has = false;
+    if (dx == 0) { if (!(x0 < px && px < x1)) return false; }
+    else {
+        int a = dx > 0 ? (x0 - px) : (px - x1), b = dx > 0 ? (x1 - px) : (px - x0), d = dx > 0 ? dx : -dx;
+        ln = a; ld = d; un = b; ud = d; has = true;
+    }
+    if (dy == 0) { if (!(y0 < py && py < y1)) return false; }
+    else {
+        int a = dy > 0 ? (y0 - py) : (py - y1), b = dy > 0 ? (y1 - py) : (py - y0), d = dy > 0 ? dy : -dy;
+        if (!has || rs_frac_lt(ln, ld, a, d)) { ln = a; ld = d; }
+        if (!has || rs_frac_lt(b, d, un, ud)) { un = b; ud = d; }
+        has = true;
+    }
+    if (!has) return true;                    // degenerate segment strictly inside
+    return rs_frac_lt(ln, ld, un, ud) && rs_frac_lt(ln, ld, 1, 1) && rs_frac_lt(0, 1, un, ud);
+}
+
+__device__ __forceinline__ int rs_orient(int ax, int ay, int bx, int by, int cx, int cy) {
+    int64_t v = (int64_t)(bx - ax) * (cy - ay) - (int64_t)(by - ay) * (cx - ax);
+    return (v > 0) - (v < 0);
+}
+__device__ __forceinline__ bool rs_on_seg(int ax, int ay, int bx, int by, int cx, int cy) {
+    return min(ax, bx) <= cx && cx <= max(ax, bx) && min(ay, by) <= cy && cy <= max(ay, by);
+}
+// vis.intersect(ls1, ls2, eps) on the lattice: the closed segments share a point
+__device__ __forceinline__ bool rs_segs_intersect(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
+    int o1 = rs_orient(ax, ay, bx, by, cx, cy), o2 = rs_orient(ax, ay, bx, by, dx, dy);
+    int o3 = rs_orient(cx, cy, dx, dy, ax, ay), o4 = rs_orient(cx, cy, dx, dy, bx, by);
+    if (o1 != o2 && o3 != o4) return true;
+    if (o1 == 0 && rs_on_seg(ax, ay, bx, by, cx, cy)) return true;
+    if (o2 == 0 && rs_on_seg(ax, ay, bx, by, dx, dy)) return true;
+    if (o3 == 0 && rs_on_seg(cx, cy, dx, dy, ax, ay)) return true;
+    if (o4 == 0 && rs_on_seg(cx, cy, dx, dy, bx, by)) return true;
+    return false;
+}
+
+// edge e of a rectangle in the reference's line_segs order (:1000-1005)
+__device__ __forceinline__ void rs_edge(int e, int x0, int y0, int x1, int y1, int& ax, int& ay, int& bx, int& by) {
+    ax = (e < 2) ? x0 : x1; ay = (e < 2) ? y0 : y1;
+    bx = (e == 0 || e == 2) ? x0 : x1;
+    by = (e == 0 || e == 2) ? y1 : y0;
+}
+
+// vis.boundary_distance(Line_Segment(p,q), rect) < 0.001, exact
+__device__ __forceinline__ bool rs_seg_rect_close(int px, int py, int qx, int qy, int x0, int y0, int x1, int y1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int ax, ay, bx, by; rs_edge(e, x0, y0, x1, y1, ax, ay, bx, by);
+        if (rs_segs_intersect(px, py, qx, qy, ax, ay, bx, by)) return true;
+    }
+    int dx = qx - px, dy = qy - py;
+    int64_t len2 = (int64_t)dx * dx + (int64_t)dy * dy;
+    if (len2 == 0) return false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int cx = (c >= 2) ? x1 : x0, cy = (c == 1 || c == 2) ? y1 : y0;
+        int64_t dot = (int64_t)(cx - px) * dx + (int64_t)(cy - py) * dy;
+        if (dot >= 0 && dot <= len2) {
+            int64_t cr = (int64_t)(cx - px) * dy - (int64_t)(cy - py) * dx;
+            if (cr * cr * 1000000ll < len2) return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ double rs_dist_pt_axis_seg(int px, int py, int ax, int ay, int bx, int by) {
+    int cx = min(max(px, min(ax, bx)), max(ax, bx));
+    int cy = min(max(py, min(ay, by)), max(ay, by));
+    return rs_dist_i(px, py, cx, cy);
+}
+
+__device__ __forceinline__ bool rs_visible(const RsGeo& g, int px, int py, int qx, int qy) {
+    for (int o = 0; o < g.n; ++o) {
+        int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+        if (rs_seg_hits_open_rect(px, py, qx, qy, x0, y0, x1, y1)) return false;
+    }
+    return true;
+}
+
+// world.shortest_path(source, detector).length() (:491-493): Euclid when visible, else best detour
+// through a rectangle vertex whose geodesic distance from the source was cached at reset.
+__device__ __forceinline__ double rs_shortest_path(const RsGeo& g, const double* dsrc, int N, int n,
+                                                   int sx, int sy, int px, int py) {
+    if (rs_visible(g, sx, sy, px, py)) return rs_dist_i(sx, sy, px, py);
+    double best = INFINITY;
+    for (int v = 0; v < 4 * g.n; ++v) {
+        double d = dsrc[(size_t)v * N + n];
+        if (d < INFINITY) {
+            int vx, vy; g.vertex(v, vx, vy);
+            if (rs_visible(g, vx, vy, px, py)) {
+                double c = d + rs_dist_i(vx, vy, px, py);
+                if (c < best) best = c;
+            }
+        }
+    }
+    return best;
+}
+
+// is_intersect (:1133-1146) for a detector at (px,py)
+__device__ __forceinline__ bool rs_is_intersect(const RsGeo& g, int px, int py, int sx, int sy, double euc, double sp) {
+    for (int o = 0; o < g.n; ++o) {
+        int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+        if (rs_seg_rect_close(px, py, sx, sy, x0, y0, x1, y1) && !rs_isclose_abs(sqrt(euc), sp, 0.1)) return true;
+    }
+    return false;
+}
+
+// in_obstruction (:1148-1170): first rectangle that contains the point (closed), then strict test on it
+__device__ __forceinline__ bool rs_in_obstruction(const RsGeo& g, int px, int py) {
+    for (int o = 0; o < g.n; ++o) {
+        int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+        if (x0 <= px && px <= x1 && y0 <= py && py <= y1) return (x0 < px && px < x1 && y0 < py && py < y1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ bool rs_pt_in_closed_eps(double qx, double qy, int x0, int y0, int x1, int y1) {
+    double dx = fmax(fmax((double)x0 - qx, 0.0), qx - (double)x1);
+    double dy = fmax(fmax((double)y0 - qy, 0.0), qy - (double)y1);
+    return sqrt(dx * dx + dy * dy) <= 0.0000001;
+}
+
+// obstruction_sensors (:1172-1261) + correct_coords (:1263-1306).  Writes the 8 readings (float64
+// values rounded once to float32, as the PPO buffer does) to out[0..7] (an LDS row).
+template <bool HAS_OBS>
+__device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, int px, int py, float* out, uint32_t& err) {
+    double d8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d8[i] = 0.0;
+    if (HAS_OBS && g.n > 0) {
+        uint64_t cnt = 0;      // obs_idx_ls packed 8 bits per obstacle
+        int ones = 0;
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+            int sx_, sy_; rs_action_step(idx, sx_, sy_);
+            int qx = px + sx_, qy = py + sy_;
+            int inter = 0;
+            double dmax = 0.0;
+            for (int o = 0; o < g.n; ++o) {
+                int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+                double m = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int ax, ay, bx, by; rs_edge(e, x0, y0, x1, y1, ax, ay, bx, by);
+                    if (inter < 2 && rs_segs_intersect(ax, ay, bx, by, px, py, qx, qy)) {
+                        double od = rs_dist_pt_axis_seg(px, py, ax, ay, bx, by);
+                        double ld = (110.0 - od) / 110.0;
+                        m = fmax(m, ld);       // max(seg_dist) with the untouched entries at 0.0
+                        inter += 1;
+                        cnt += 1ull << (8 * o);
+                    }
+                }
+                if (inter > 0 && m > dmax) dmax = m;
+            }
+            d8[idx] = dmax;
+            ones += (dmax == 1.0) ? 1 : 0;
+        }
+        if (ones > 3) {
+            // argmax = max(zip(obs_idx_ls, self.poly))[1]: count, then vertex list lexicographically
+            int best = 0;
+            for (int k = 1; k < g.n; ++k) {
+                int ck = (int)((cnt >> (8 * k)) & 0xff), cb = (int)((cnt >> (8 * best)) & 0xff);
+                bool gt;
+                if (ck != cb) gt = ck > cb;
+                else {
+                    int a0 = g.get(k, 0), a1 = g.get(k, 1), a2 = g.get(k, 2), a3 = g.get(k, 3);
+                    int b0 = g.get(best, 0), b1 = g.get(best, 1), b2 = g.get(best, 2), b3 = g.get(best, 3);
+                    // key (x0,y0,x0,y1,x1,y1,x1,y0) -> distinct components in order x0,y0,y1,x1
+                    if (a0 != b0) gt = a0 > b0; else if (a1 != b1) gt = a1 > b1;
+                    else if (a3 != b3) gt = a3 > b3; else gt = a2 > b2;
+                }
+                if (gt) best = k;
+            }
+            int x0, y0, x1, y1; g.rect(best, x0, y0, x1, y1);
+            double qx[8], qy[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) { qx[a] = (double)px; qy[a] = (double)py; }
+            uint32_t chk = 0;
+            int it = 0;
+            while (chk == 0) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    int cx, cy; rs_dir_coeff(a, cx, cy);
+                    qx[a] = qx[a] + (double)cx * 0.1;
+                    qy[a] = qy[a] + (double)cy * 0.1;
+                    if (rs_pt_in_closed_eps(qx[a], qy[a], x0, y0, x1, y1)) chk |= 1u << a;
+                }
+                if (++it >= RS_CORRECT_CAP) { err |= RS_ENVERR_CORRECT_CAP; break; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d8[i] = 0.0;
+            if (__popc(chk) >= 4) {
+#pragma unroll
+                for (int ii = 0; ii < 8; ii += 2) {
+                    int lo = (ii + 7) & 7, hi = (ii + 1) & 7;
+                    if ((chk >> lo & 1u) && (chk >> hi & 1u)) { d8[ii] = 1.0; d8[lo] = 1.0; d8[hi] = 1.0; }
+                }
+            }
+        }
+    }
+    if (P.enforce) {
+        if ((double)px - 110.0 < (double)P.bx0) d8[0] = (110.0 - fabs((double)(px - P.bx0))) / 110.0;
+        if ((double)py - 110.0 < (double)P.by0) d8[6] = (110.0 - fabs((double)(py - P.by0))) / 110.0;
+        if ((double)P.bx1 <= (double)px + 110.0) d8[4] = (110.0 - fabs((double)(P.bx1 - px))) / 110.0;
+        if ((double)P.by1 <= (double)py + 110.0) d8[2] = (110.0 - fabs((double)(P.by1 - py))) / 110.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)d8[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Outputs of one env (lane) for one lock-step.  obs rows go to an LDS tile (coalesced copy-out by the
+// caller); the scalar outputs go straight to HBM.
+struct RsOut {
+    float* obs_row;        // LDS: this lane's [A][11] rows, row stride RS_OBS_DIM
+    float* reward;         // [N,A] or null
+    float* team;           // [N] or null
+    uint8_t* done;         // [N,A] or null
+    uint8_t* oob;          // [N,A] or null
+    int32_t* oobc;         // [N,A] or null
+    uint8_t* blocked;      // [N,A] or null
+    uint8_t* collision;    // [N,A] or null
+};
+
+// RadSearch.step for env n (one lane).  act_of(a) returns agent a's action (0..8) or RS_ACT_NONE.
+// Mirrors step :443-728 / agent_step :460-613; agents are processed in id order because `done`, the
+// team reward and the collision rule are order dependent.
+template <bool HAS_OBS, typename ActFn>
+__device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo& g, int n, ActFn act_of, const RsOut& O) {
+    const int N = P.N, A = P.A;
+    const int sx = P.src_x[n], sy = P.src_y[n];
+    const int intensity = P.intensity[n], bkg = P.bkg[n];
+    int iter_count = P.iter_count[n];
+    const uint32_t episode = P.episode[n], t = P.tstep[n];
+    uint32_t err = 0;
+    bool done = P.done[n] != 0;
+    const uint32_t k0 = P.seed, k1 = P.env_id_base + (uint32_t)n;
+
+    // collision rule (:908-910): an agent stalls when >1 agents propose its tentative cell.  Proposals
+    // are functions of the pre-step positions only, so they are evaluated up front.
+    uint32_t coll_mask = 0;
+    bool any_none = false;
+    for (int i = 0; i < A; ++i) any_none |= (act_of(i) == RS_ACT_NONE);
+    if (A > 1 && !any_none) {
+        for (int i = 0; i < A; ++i) {
+            int dxi, dyi; rs_action_step(act_of(i), dxi, dyi);
+            int tx = P.ax[(size_t)i * N + n] + dxi, ty = P.ay[(size_t)i * N + n] + dyi;
+            int cnt = 0;
+            for (int j = 0; j < A; ++j) {
+                int dxj, dyj; rs_action_step(act_of(j), dxj, dyj);
+                cnt += (P.ax[(size_t)j * N + n] + dxj == tx && P.ay[(size_t)j * N + n] + dyj == ty) ? 1 : 0;
+            }
+            if (cnt > 1) coll_mask |= 1u << i;
+        }
+    }
+
+    double max_reward = 0.0;
+    bool have_max = false;
+    for (int a = 0; a < A; ++a) {
+        const size_t ia = (size_t)a * N + n;
+        int act = act_of(a);
+        if (act < 0) act = RS_IDLE;                         // -1 == idle (:620-623)
+        if (act > RS_ACT_NONE) { err |= RS_ENVERR_BAD_ACTION; act = RS_IDLE; }
+        int x = P.ax[ia], y = P.ay[ia];
+        double sp = P.sp[ia], prev = P.prev[ia];
+        int oobc = P.oobc[ia];
+        uint8_t fl = P.aflags[ia] & (RS_AF_BLOCKED | RS_AF_INTERSECT);   // oob/collision reset each step (:479-480)
+        bool moved = false;
+        int px = x, py = y;                                  // agent.detector after take_action
+        // ---- take_action :876-946
+        if (act != RS_ACT_NONE) {
+            if (coll_mask >> a & 1u) {
+                fl |= RS_AF_COLLISION;
+            } else {
+                int dx, dy; rs_action_step(act, dx, dy);
+                int tx = x + dx, ty = y + dy;
+                bool roll_back = false;
+                if (P.enforce) {
+                    if ((tx < P.bx0 || ty < P.by0) || (P.bx1 <= tx || P.by1 <= ty)) { fl |= RS_AF_OOB; oobc += 1; roll_back = true; }
+                } else {
+                    bool lower_b = x < P.sa_x0 || y < P.sa_y0, upper_b = P.sa_x1 < x || P.sa_y1 < y;
+                    if (lower_b || upper_b) { fl |= RS_AF_OOB; oobc += 1; }
+                }
+                if (HAS_OBS && g.n > 0 && rs_in_obstruction(g, tx, ty)) { roll_back = true; fl |= RS_AF_BLOCKED; }
+                if (!roll_back) { x = tx; y = ty; px = tx; py = ty; moved = true; }
+            }
+        }
+        // ---- distances, line of sight, measurement, reward :486-567
+        double euc = rs_dist_i(x, y, sx, sy);               // == the stale euc_dist when stalled (position unchanged)
+        double reward;
+        if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, sx, sy, x, y) : euc;
+        bool inter = (HAS_OBS && g.n > 0) ? rs_is_intersect(g, px, py, sx, sy, euc, sp) : false;
+        fl = (uint8_t)((fl & ~RS_AF_INTERSECT) | (inter ? RS_AF_INTERSECT : 0));
+        double lam;
+        if (inter) lam = (double)bkg;
+        else {
+            double r = euc;
+            if (r == 0.0) { err |= RS_ENVERR_ZERO_DIST; r = 1.0; }
+            lam = (P.falloff ? ((double)intensity / (r * r)) : ((double)intensity / r)) + (double)bkg;
+        }
+        int64_t meas = rs_poisson(lam, t, episode, RS_STREAM_STEP + (uint32_t)a, k0, k1);
+        if (moved) {
+            if (sp < 110.0) { reward = 0.1; done = true; }
+            else if (sp < prev) { reward = 0.1; prev = sp; }
+            else reward = ((act == RS_IDLE) ? -1.0 : -0.5) * sp / P.max_dist;
+        } else {
+            if (act == RS_IDLE && !(fl & RS_AF_COLLISION)) err |= RS_ENVERR_IDLE_STALL;
+            reward = -0.5 * sp / P.max_dist;
+        }
+        reward = rs_round2(reward);
+        // ---- observation :570-593
+        float* row = O.obs_row + a * RS_OBS_DIM;
+        row[0] = (float)(double)meas;
+        row[1] = (float)(((double)x + 0.0) * P.scale);
+        row[2] = (float)(((double)y + 0.0) * P.scale);
+        if ((HAS_OBS && g.n > 0) || P.enforce) rs_sensors<HAS_OBS>(P, g, px, py, row + 3, err);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) row[3 + i] = 0.0f;
+        }
+        // ---- team reward with the falsy-reset quirk :662-665
+        if (!have_max || max_reward == 0.0) { max_reward = reward; have_max = true; }
+        else if (max_reward < reward) max_reward = reward;
+        // ---- write back
+        P.ax[ia] = x; P.ay[ia] = y; P.sp[ia] = sp; P.prev[ia] = prev; P.oobc[ia] = oobc; P.aflags[ia] = fl;
+        const size_t oa = (size_t)n * A + a;
+        if (O.reward) O.reward[oa] = (float)reward;
+        if (O.done) O.done[oa] = done ? 1 : 0;
+        if (O.oob) O.oob[oa] = (fl & RS_AF_OOB) ? 1 : 0;
+        if (O.oobc) O.oobc[oa] = oobc;
+        if (O.blocked) O.blocked[oa] = (fl & RS_AF_BLOCKED) ? 1 : 0;
+        if (O.collision) O.collision[oa] = (fl & RS_AF_COLLISION) ? 1 : 0;
+    }
+    if (O.team) O.team[n] = (float)max_reward;
+    P.done[n] = done ? 1 : 0;
+    P.iter_count[n] = iter_count + 1;
+    P.tstep[n] = t + 1;
+    if (err) P.err[n] |= err;
+}

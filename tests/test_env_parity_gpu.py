@@ -1,0 +1,191 @@
+"""GPU parity proper: the HIP kernels, called through the C ABI (radiation_ppo_amd.envs -> ctypes ->
+librs_hip.so), against the oracle on identical Philox streams.  Bar: bit-exact on every output --
+observations (float32 of the oracle's float64), rewards, done latch, info flags, positions, shortest-
+path distances (float64) -- for every env and step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.radsearch_oracle import PhiloxDraws, PhiloxGeomDraws, RadSearchOracle, sample_layout
+
+pytestmark = pytest.mark.gpu
+
+SEED = 289714752   # robust_seed(2) of the reference (main.py:478)
+
+
+def _make(N, A, obst, enforce, group=1, base=0, falloff="reference"):
+    from radiation_ppo_amd.envs import RadSearchVec
+    vec = RadSearchVec(N, number_agents=A, obstruction_count=obst, enforce_grid_boundaries=enforce, seed=SEED,
+                       env_id_base=base, geom_group_size=group, falloff=falloff)
+    oracles = []
+    geom = {}
+    for n in range(N):
+        layout_fn = None
+        if group > 1 and obst != 0:
+            gi = n // group
+            if gi not in geom:
+                geom[gi] = {"draws": PhiloxGeomDraws(SEED, base + gi * group), "epoch": 0, "rects": None, "stamp": -1}
+
+            def layout_fn(gi=gi):
+                st = geom[gi]
+                if st["stamp"] != st["want"]:
+                    st["draws"].begin(st["epoch"])
+                    st["rects"] = sample_layout(st["draws"], obst)
+                    st["epoch"] += 1
+                    st["stamp"] = st["want"]
+                return st["rects"]
+            geom[gi]["want"] = 0
+        # the oracle constructor performs the first reset (like the reference's __post_init__)
+        oracles.append((n, layout_fn))
+    return vec, oracles, geom
+
+
+def _compare(vec, outs, refs, rets, tag):
+    obs, rew, team, done, info = (t.cpu().numpy() if torch.is_tensor(t) else t for t in outs[:4]) + (outs[4],)
+    oob = info["out_of_bounds"].cpu().numpy()
+    oobc = info["out_of_bounds_count"].cpu().numpy()
+    blk = info["blocked"].cpu().numpy()
+    col = info["collision"].cpu().numpy()
+    x = vec.state("x").cpu().numpy()
+    y = vec.state("y").cpu().numpy()
+    sp = vec.state("sp").cpu().numpy()
+    prev = vec.state("prev").cpu().numpy()
+    for n, (env, ret) in enumerate(zip(refs, rets)):
+        if ret is None:
+            continue
+        o, r, d, i = ret
+        for a in range(env.number_agents):
+            exp = np.asarray(o[a], dtype=np.float64).astype(np.float32)
+            assert np.array_equal(obs[n, a], exp), (tag, n, a, obs[n, a], exp)
+            assert rew[n, a] == np.float32(r["individual_reward"][a]), (tag, n, a, rew[n, a], r["individual_reward"][a])
+            assert bool(done[n, a]) == bool(d[a]), (tag, n, a)
+            assert bool(oob[n, a]) == i[a]["out_of_bounds"] and int(oobc[n, a]) == i[a]["out_of_bounds_count"], (tag, n, a)
+            assert bool(blk[n, a]) == i[a]["blocked"], (tag, n, a)
+            ag = env.agents[a]
+            assert bool(col[n, a]) == ag.collision, (tag, n, a)
+            assert (x[a, n], y[a, n]) == ag.det, (tag, n, a)
+            assert sp[a, n] == ag.sp_dist and prev[a, n] == ag.prev_det_dist, (tag, n, a, sp[a, n], ag.sp_dist)
+        assert team[n] == np.float32(r["team_reward"]), (tag, n)
+
+
+def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="reference", seed=0):
+    vec, specs, geom = _make(N, A, obst, enforce, group, base, falloff)
+    refs = [RadSearchOracle(PhiloxDraws(SEED, base + n), number_agents=A, obstruction_count=obst,
+                            enforce_grid_boundaries=enforce, falloff=falloff, layout_fn=fn) for n, fn in specs]
+    outs = vec.reset()
+    torch.cuda.synchronize()
+    _compare(vec, outs, refs, [e._ret for e in refs], "reset0")
+    rng = np.random.default_rng(seed)
+    t_in_ep = np.zeros(N, dtype=np.int64)
+    for t in range(steps):
+        acts = rng.integers(0, 9, size=(N, A)).astype(np.int8)
+        if t % 11 == 5:
+            acts[:, 0] = -1                      # -1 == idle (rad_search_env.py:620-623)
+        outs = vec.step(torch.from_numpy(acts).cuda())
+        rets = [e.step({a: (8 if acts[n, a] == -1 else int(acts[n, a])) for a in range(A)}) for n, e in enumerate(refs)]
+        torch.cuda.synchronize()
+        _compare(vec, outs, refs, rets, f"step{t}")
+        t_in_ep += 1
+        mask = np.array([e.done for e in refs]) | (t_in_ep >= ep_len)
+        if t % 17 == 16:                          # epoch boundary: everything resets with epoch_end set
+            mask[:] = True
+            vec.set_epoch_end()
+            for e in refs:
+                e.epoch_end = True
+            for st in geom.values():
+                st["want"] += 1
+        if mask.any():
+            outs = vec.reset(torch.from_numpy(mask.astype(np.uint8)).cuda())
+            rets = [e.reset() if mask[n] else None for n, e in enumerate(refs)]
+            torch.cuda.synchronize()
+            _compare(vec, outs, refs, rets, f"reset@{t}")
+            t_in_ep[mask] = 0
+    assert vec.error_flags() == 0
+    assert all(e.err == 0 for e in refs)
+
+
+def test_obstacle_free_single_agent_enforced():
+    _run(N=200, A=1, obst=0, enforce=True, steps=70)
+
+
+def test_obstacle_free_single_agent_unenforced():
+    _run(N=130, A=1, obst=0, enforce=False, steps=50)
+
+
+@pytest.mark.parametrize("A", [2, 4])
+def test_obstacle_free_multi_agent(A):
+    _run(N=96, A=A, obst=0, enforce=True, steps=60)
+
+
+def test_obstacles_single_agent():
+    _run(N=96, A=1, obst=5, enforce=True, steps=60, seed=3)
+
+
+def test_obstacles_random_count_multi_agent():
+    _run(N=64, A=3, obst=-1, enforce=True, steps=50, seed=4)
+
+
+def test_obstacles_max_count_unenforced():
+    _run(N=40, A=2, obst=7, enforce=False, steps=40, seed=5)
+
+
+def test_shared_layout_per_wave():
+    _run(N=128, A=1, obst=4, enforce=True, steps=40, group=64, seed=6)
+
+
+def test_shared_layout_small_groups():
+    _run(N=48, A=2, obst=3, enforce=True, steps=36, group=4, seed=7)
+
+
+def test_env_id_base_sharding_equivalence():
+    """Envs are keyed by GLOBAL id: a rank that owns envs [64,128) reproduces the second half of a
+    128-env job exactly (multi-GPU sharding does not change results)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    full = RadSearchVec(128, obstruction_count=3, enforce_grid_boundaries=True, seed=SEED)
+    half = RadSearchVec(64, obstruction_count=3, enforce_grid_boundaries=True, seed=SEED, env_id_base=64)
+    full.reset(); half.reset()
+    rng = np.random.default_rng(9)
+    for t in range(30):
+        acts = rng.integers(0, 9, size=(128, 1)).astype(np.int8)
+        of = full.step(torch.from_numpy(acts).cuda())
+        oh = half.step(torch.from_numpy(acts[64:].copy()).cuda())
+        assert torch.equal(of[0][64:], oh[0]) and torch.equal(of[1][64:], oh[1]) and torch.equal(of[3][64:], oh[3])
+
+
+def test_inverse_square_falloff_option():
+    _run(N=64, A=1, obst=0, enforce=True, steps=30, falloff="inverse_square")
+
+
+def test_bad_action_flag_and_adapter_errors():
+    from radiation_ppo_amd.envs import RadSearchVec
+    vec = RadSearchVec(8, enforce_grid_boundaries=True, seed=1)
+    vec.reset()
+    a = torch.full((8, 1), 12, dtype=torch.int8, device="cuda")
+    vec.step(a)
+    assert vec.error_flags() & 8
+
+
+def test_dict_api_adapter_matches_oracle():
+    """The gym-style adapter (RadSearch) returns the reference's 4-tuple of dicts."""
+    from radiation_ppo_amd.envs import RadSearch
+    env = RadSearch(number_agents=2, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED)
+    ref = RadSearchOracle(PhiloxDraws(SEED, 0), number_agents=2, obstruction_count=0, enforce_grid_boundaries=True)
+    assert env.search_area == ((200.0, 200.0), (2200.0, 200.0), (2200.0, 2200.0), (200.0, 2200.0))
+    assert env.observation_space.shape == (11,) and env.number_actions == 9 and env.scale == 1 / 2200.0
+    assert env.src_coords == (float(ref.src[0]), float(ref.src[1]))
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        act = {0: int(rng.integers(0, 9)), 1: int(rng.integers(0, 9))}
+        o, r, d, i = env.step(act)
+        ro, rr, rd, ri = ref.step(act)
+        for a in range(2):
+            assert np.array_equal(o[a].astype(np.float32), np.asarray(ro[a]).astype(np.float32))
+            assert r["individual_reward"][a] == rr["individual_reward"][a]
+            assert d[a] == rd[a] and i[a] == ri[a]
+        assert r["team_reward"] == rr["team_reward"]
+        if t % 13 == 12:
+            env.epoch_end = True
+            ref.epoch_end = True
+            o, r, d, i = env.reset()
+            ro, rr, rd, ri = ref.reset()
+            assert np.array_equal(o[0].astype(np.float32), np.asarray(ro[0]).astype(np.float32))
