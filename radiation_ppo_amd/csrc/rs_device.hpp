@@ -433,7 +433,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
     const int sx = P.src_x[n], sy = P.src_y[n];
     const int intensity = P.intensity[n], bkg = P.bkg[n];
     int iter_count = P.iter_count[n];
-    const uint32_t episode = P.episode[n], t = P.tstep[n];
+    const uint32_t episode = P.episode[n] - 1u, t = P.tstep[n];   // episode[] holds the NEXT episode id
     uint32_t err = 0;
     bool done = P.done[n] != 0;
     const uint32_t k0 = P.seed, k1 = P.env_id_base + (uint32_t)n;

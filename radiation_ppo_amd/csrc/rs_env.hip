@@ -239,9 +239,9 @@ __global__ void __launch_bounds__(64) rs_reset_kernel(RsParams P, const uint8_t*
         // ---- initial observation: step(None) (:794-797)
         RsOut o = O;
         o.obs_row = tile + lane * rs_tile_stride(A);
+        P.episode[n] = episode + 1;       // draws of this episode are keyed by `episode`
         rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
         P.iter_count[n] = 0;
-        P.episode[n] = episode + 1;
     }
     __syncthreads();
     rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);

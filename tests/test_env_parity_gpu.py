@@ -41,7 +41,8 @@ def _make(N, A, obst, enforce, group=1, base=0, falloff="reference"):
 
 
 def _compare(vec, outs, refs, rets, tag):
-    obs, rew, team, done, info = (t.cpu().numpy() if torch.is_tensor(t) else t for t in outs[:4]) + (outs[4],)
+    obs, rew, team, done = (t.cpu().numpy() for t in outs[:4])
+    info = outs[4]
     oob = info["out_of_bounds"].cpu().numpy()
     oobc = info["out_of_bounds_count"].cpu().numpy()
     blk = info["blocked"].cpu().numpy()
