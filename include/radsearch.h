@@ -11,9 +11,6 @@
  *   rs_set_epoch_end <- `env.epoch_end = True` algos/multiagent/train.py:482-484
  *   rs_gae       <- PPOBuffer.GAE_advantage_and_rewardsToGO   algos/multiagent/ppo.py:391-423
  *                   (discount_cumsum ppo.py:62-85), one call for the whole [T, N*A] buffer
- *   rs_rollout   <- the collector loop        algos/multiagent/train.py:332-548 with the
- *                   FF_core.ActorCritic policy (NeuralNetworkCores/FF_core.py:42-129)
- *   rs_ppo_loss_grad <- AgentPPO.update_rada2c loss/backward  ppo.py:1206-1256
  *
  * Conventions
  *   - plain C: pointers and sizes only, no torch types, no exceptions; return 0 = RS_OK.
@@ -114,6 +111,12 @@ int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float
  * done[n,a] is the env-wide latch as seen when agent a returned (rad_search_env.py:509,613). */
 int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, float* team, uint8_t* done,
             const rs_info* info, rs_stream_t stream);
+
+/* Uniforms for action sampling, u[n,a] in [0,1) with 24 random bits, from the env's own Philox stream:
+ * key (seed, global env id), counter (0, step index of the NEXT rs_step, episode, 32 + a).  The host
+ * (and the fused collector) sample a = #{j : cdf_j <= u}, so a trajectory is a pure function of
+ * (seed, env id, policy).  Replaces Categorical(probs).sample() (FF_core.py:101-104). */
+int rs_action_uniforms(rs_handle* h, float* u, rs_stream_t stream);
 
 /* host copy of the OR of all per-env error bits (synchronises `stream`; debugging/adapters only) */
 int rs_error_flags(rs_handle* h, rs_stream_t stream, uint32_t* flags_out);

@@ -48,6 +48,7 @@ SYMBOLS = [
                            C.POINTER(RsInfo), C.c_void_p]),
     ("rs_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(RsInfo), C.c_void_p]),
+    ("rs_action_uniforms", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rs_error_flags", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                          C.c_int32, C.c_double, C.c_double, C.c_void_p]),

@@ -33,6 +33,7 @@
 
 #define RS_STREAM_RESET 0u
 #define RS_STREAM_STEP 1u      // + agent id
+#define RS_STREAM_ACT 32u      // + agent id
 #define RS_STREAM_GEOM 64u
 
 // ---------------------------------------------------------------------------------------------

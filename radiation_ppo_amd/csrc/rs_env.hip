@@ -247,6 +247,16 @@ __global__ void __launch_bounds__(64) rs_reset_kernel(RsParams P, const uint8_t*
     rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);
 }
 
+__global__ void __launch_bounds__(64) rs_action_uniform_kernel(RsParams P, float* __restrict__ u) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= P.N) return;
+    const uint32_t episode = P.episode[n] - 1u, t = P.tstep[n];
+    for (int a = 0; a < P.A; ++a) {
+        u32x4 o = philox4x32_10(0u, t, episode, RS_STREAM_ACT + (uint32_t)a, P.seed, P.env_id_base + (uint32_t)n);
+        u[(size_t)n * P.A + a] = (float)(o.x >> 8) * (1.0f / 16777216.0f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: GAE(lambda) + rewards-to-go, PPOBuffer.GAE_advantage_and_rewardsToGO (ppo.py:391-423) for the
 // whole time-major buffer.  One column (env x agent trajectory stream) per lane; a reverse scan in
@@ -456,6 +466,13 @@ int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, floa
     size_t lds = tile_bytes(P.A) + (P.obstruction_count != 0 ? RS_MAX_VERT * RS_WAVE * 4 : 0);
     if (P.obstruction_count != 0) hipLaunchKernelGGL(rs_step_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_step_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_action_uniforms(rs_handle* h, float* u, rs_stream_t stream) {
+    if (!h || !u) return RS_ERR_INVALID_ARG;
+    const RsParams& P = h->P;
+    hipLaunchKernelGGL(rs_action_uniform_kernel, dim3((P.N + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), P, u);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

@@ -141,6 +141,12 @@ class RadSearchVec:
                    "rs_step")
         return self._outs()
 
+    def action_uniforms(self, out: torch.Tensor) -> torch.Tensor:
+        """u[N,A] in [0,1) for inverse-CDF action sampling, from each env's own Philox stream (rs_action_uniforms)."""
+        assert out.dtype == torch.float32 and out.numel() == self.num_envs * self.number_agents and out.is_contiguous()
+        _lib.check(self.lib.rs_action_uniforms(self._h, out.data_ptr(), self._stream()), "rs_action_uniforms")
+        return out
+
     def error_flags(self) -> int:
         f = C.c_uint32(0)
         _lib.check(self.lib.rs_error_flags(self._h, self._stream(), C.byref(f)), "rs_error_flags")

@@ -1,0 +1,359 @@
+"""PPO side of the hot path, on the same device as the env so rollouts never leave HBM.
+
+Mirrors (paths relative to the reference root):
+  FFActorCritic       <- algos/multiagent/NeuralNetworkCores/FF_core.py:42-129 (2x64 tanh MLP actor/critic;
+                         same module names, so state_dicts interchange)
+  DeviceWelford       <- RADTEAM_core.py:188-277 StatisticStandardization, batched over [N, A]
+  RolloutBuffer       <- algos/multiagent/ppo.py:220-502 PPOBuffer (store / GAE / get), time-major [T, N, A]
+  VecAgentPPO         <- ppo.py:505-1355 AgentPPO for the 'ff'/'mlp' architecture (loss form of
+                         update_rada2c, ppo.py:1206-1256: clipped surrogate - 0.01*MSE + alpha*entropy,
+                         per-episode means, KL early stop at 1.5*target_kl, one Adam over actor+critic,
+                         StepLR(100, 0.99)); N envs play the role of the reference's N MPI ranks
+                         (gradient = mean over ranks of each rank's mean over its episodes).
+"""
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib
+from .envs import RadSearchVec, gae as rs_gae_call
+
+
+class FFActorCritic(nn.Module):
+    """FF_core.ActorCritic (discrete branch): Linear(11,64)-Tanh-Linear(64,64)-Tanh-Linear(64,8)-Softmax and
+    the same-shape critic ending in Linear(64,1)."""
+
+    def __init__(self, state_dim: int = 11, action_dim: int = 8, hidden: int = 64):
+        super().__init__()
+        self.actor = nn.Sequential(nn.Linear(state_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                   nn.Linear(hidden, action_dim), nn.Softmax(dim=-1))
+        self.critic = nn.Sequential(nn.Linear(state_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                    nn.Linear(hidden, 1))
+
+    def logits(self, x: torch.Tensor) -> torch.Tensor:
+        for layer in list(self.actor)[:-1]:
+            x = layer(x)
+        return x
+
+    @torch.no_grad()
+    def act(self, x: torch.Tensor, u: torch.Tensor):
+        """Sample by inverse CDF with the caller's uniforms u in [0,1): a = #{j : cdf_j <= u} (clamped)."""
+        logp_all = torch.log_softmax(self.logits(x), dim=-1)
+        cdf = torch.cumsum(logp_all.exp(), dim=-1)
+        a = (cdf <= u.unsqueeze(-1)).sum(dim=-1).clamp_(max=logp_all.shape[-1] - 1)
+        logp = logp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1)
+        v = self.critic(x).squeeze(-1)
+        return a, logp, v
+
+    def evaluate(self, x: torch.Tensor, a: torch.Tensor):
+        logp_all = torch.log_softmax(self.logits(x), dim=-1)
+        logp = logp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1)
+        ent = -(logp_all.exp() * logp_all).sum(dim=-1)
+        v = self.critic(x).squeeze(-1)
+        return logp, v, ent
+
+
+class DeviceWelford:
+    """StatisticStandardization (RADTEAM_core.py:188-277) for every (env, agent) at once, float64."""
+
+    def __init__(self, shape, device):
+        self.count = torch.zeros(shape, dtype=torch.float64, device=device)
+        self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
+        self.sq = torch.zeros(shape, dtype=torch.float64, device=device)
+        self.std = torch.ones(shape, dtype=torch.float64, device=device)
+
+    def update(self, reading: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
+        x = reading.double()
+        count = self.count + 1
+        first = count == 1
+        mean_new = torch.where(first, x, self.mean + (x - self.mean) / count)
+        sq_new = torch.where(first, self.sq, self.sq + (x - self.mean) * (x - mean_new))
+        std_new = torch.where(first, self.std, torch.clamp(torch.sqrt(sq_new / torch.clamp(count - 1, min=1)), min=1.0))
+        if mask is not None:
+            m = mask.view(-1, *([1] * (x.dim() - 1))).expand_as(x)
+            count = torch.where(m, count, self.count)
+            mean_new = torch.where(m, mean_new, self.mean)
+            sq_new = torch.where(m, sq_new, self.sq)
+            std_new = torch.where(m, std_new, self.std)
+        self.count, self.mean, self.sq, self.std = count, mean_new, sq_new, std_new
+
+    def standardize(self, reading: torch.Tensor) -> torch.Tensor:
+        return ((reading.double() - self.mean) / self.std).float()
+
+    def reset(self, mask: torch.Tensor) -> None:
+        m = mask.view(-1, *([1] * (self.count.dim() - 1))).expand_as(self.count)
+        self.count = torch.where(m, torch.zeros_like(self.count), self.count)
+        self.mean = torch.where(m, torch.zeros_like(self.mean), self.mean)
+        self.sq = torch.where(m, torch.zeros_like(self.sq), self.sq)
+        self.std = torch.where(m, torch.ones_like(self.std), self.std)
+
+
+class RolloutBuffer:
+    """PPOBuffer (ppo.py:220-502) for all envs and agents, time-major so that one lock-step is one
+    contiguous row: obs [T,N,A,11], act/rew/val/logp/last_val [T,N,A], cut [T,N,A] u8, source_tar [T,N,2]."""
+
+    def __init__(self, T: int, N: int, A: int, obs_dim: int, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.T, self.N, self.A = T, N, A
+        self.obs = torch.zeros(T, N, A, obs_dim, **f)
+        self.act = torch.zeros(T, N, A, dtype=torch.int64, device=device)
+        self.rew = torch.zeros(T, N, A, **f)
+        self.val = torch.zeros(T, N, A, **f)
+        self.logp = torch.zeros(T, N, A, **f)
+        self.last_val = torch.zeros(T, N, A, **f)
+        self.cut = torch.zeros(T, N, A, dtype=torch.uint8, device=device)
+        self.source_tar = torch.zeros(T, N, 2, **f)
+        self.adv = torch.zeros(T, N, A, **f)
+        self.ret = torch.zeros(T, N, A, **f)
+
+    def finish(self, gamma: float, lam: float) -> None:
+        """GAE_advantage_and_rewardsToGO for every trajectory slice of the buffer in one kernel (rs_gae)."""
+        rs_gae_call(self.rew, self.val, self.cut, self.last_val, gamma, lam, adv=self.adv, ret=self.ret)
+
+    def episode_weights(self) -> torch.Tensor:
+        """1 / (episodes in the column * length of the sample's episode): the per-sample weight that turns
+        sums into the reference's mean-over-episodes of per-episode means (ppo.py:1191-1234)."""
+        cut = self.cut[:, :, 0].long()                     # cuts are env-wide
+        T, N = cut.shape
+        seg = torch.cumsum(cut, dim=0) - cut               # episode index of every step, per env
+        n_ep = seg[-1] + 1                                  # the last step always closes a trajectory
+        lens = torch.zeros(T, N, dtype=torch.float32, device=cut.device)
+        lens.scatter_add_(0, seg, torch.ones(T, N, dtype=torch.float32, device=cut.device))
+        w = 1.0 / (n_ep.unsqueeze(0).float() * lens.gather(0, seg))
+        return w                                            # [T, N]
+
+
+@dataclass
+class UpdateResult:
+    """ppo.py:146-157"""
+    stop_iteration: int
+    loss_policy: float
+    loss_critic: float
+    loss_predictor: float
+    kl_divergence: float
+    Entropy: float
+    ClipFrac: float
+    LocLoss: float
+    VarExplain: int = 0
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class VecAgentPPO:
+    """One agent id's networks + optimiser; the vectorised counterpart of AgentPPO (ppo.py:505-1355)."""
+
+    def __init__(self, id: int, observation_space: int = 11, action_space: int = 8, steps_per_epoch: int = 480,
+                 steps_per_episode: int = 120, number_of_agents: int = 1, actor_critic_architecture: str = "ff",
+                 train_pi_iters: int = 40, train_v_iters: int = 40, actor_learning_rate: float = 3e-4,
+                 critic_learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 0.0, clip_ratio: float = 0.2,
+                 target_kl: float = 0.07, lam: float = 0.9, device="cuda:0", **unused: Any):
+        if actor_critic_architecture not in ("ff", "mlp"):
+            raise ValueError("Unsupported Neural Network type requested")   # ppo.py:666-667
+        self.id = id
+        self.device = torch.device(device)
+        self.gamma, self.lam, self.alpha = gamma, lam, alpha
+        self.clip_ratio, self.target_kl = clip_ratio, target_kl
+        self.train_pi_iters = train_pi_iters
+        self.agent = FFActorCritic(observation_space, action_space).to(self.device)
+        self.pi_optimizer = torch.optim.Adam(self.agent.parameters(), lr=actor_learning_rate)
+        self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)   # ppo.py:205-207
+        self._flat_grad: Optional[torch.Tensor] = None
+
+    def sync_params(self) -> None:
+        """mpi_pytorch.sync_params (mpi_pytorch.py:43-49): one RCCL broadcast of the flattened parameters."""
+        if _world() > 1:
+            flat = torch.cat([p.data.view(-1) for p in self.agent.parameters()])
+            dist.broadcast(flat, src=0)
+            o = 0
+            for p in self.agent.parameters():
+                p.data.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+
+    def _allreduce_grads(self) -> None:
+        """mpi_avg_grads (mpi_pytorch.py:26-33) as ONE flattened all-reduce.  The loss weights already carry
+        1/(global env count), so the sum over ranks is the reference's average over ranks."""
+        if _world() == 1:
+            return
+        params = [p for p in self.agent.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.view(-1) for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for p in params:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def update_agent(self, X: torch.Tensor, act: torch.Tensor, adv: torch.Tensor, ret: torch.Tensor,
+                     logp_old: torch.Tensor, w: torch.Tensor) -> UpdateResult:
+        """update_agent (ppo.py:746-813) + update_rada2c (:1150-1281) on the whole batch.  w sums to 1 over
+        the GLOBAL batch (all ranks)."""
+        kk = 0
+        kl_reached = False
+        last = None
+        thr = 1.5 * self.target_kl
+        while not kl_reached and kk < self.train_pi_iters:
+            logp, v, ent = self.agent.evaluate(X, act)
+            ratio = torch.exp(logp - logp_old)
+            clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv
+            surr = torch.min(ratio * adv, clip_adv)
+            val_loss = (w * (v - ret) ** 2).sum()
+            ent_m = (w * ent).sum()
+            loss = -((w * surr).sum() - 0.01 * val_loss + self.alpha * ent_m)
+            with torch.no_grad():
+                clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
+                stats = torch.stack([(w * (logp_old - logp)).sum(), ent_m.detach(), (w * clipped.float()).sum(),
+                                     val_loss.detach(), loss.detach()])
+                if _world() > 1:
+                    dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # mpi_avg(kl) (ppo.py:1250)
+                stats_h = stats.tolist()                               # the early-stop decision needs the host
+            last = stats_h
+            if stats_h[0] < thr:
+                self.pi_optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                self._allreduce_grads()
+                self.pi_optimizer.step()
+            else:
+                kl_reached = True
+            kk += 1
+        self.pi_scheduler.step()                                       # ppo.py:799
+        return UpdateResult(stop_iteration=kk, loss_policy=last[4], loss_critic=last[3], loss_predictor=0.0,
+                            kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
+
+    def save(self, path: str) -> None:
+        torch.save(self.agent.state_dict(), path)
+
+    def load(self, path: str) -> None:
+        self.agent.load_state_dict(torch.load(path, map_location=self.device))
+
+
+def normalize_advantages(adv: torch.Tensor) -> torch.Tensor:
+    """PPOBuffer.get advantage normalisation (ppo.py:445-446) with mpi_statistics_scalar (mpi_tools.py:71-95):
+    global mean and POPULATION std over every rank's samples, no epsilon."""
+    n = torch.tensor([adv.numel()], dtype=torch.float64, device=adv.device)
+    s = adv.double().sum().view(1)
+    if _world() > 1:
+        pack = torch.cat([s, n])
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+        s, n = pack[0:1], pack[1:2]
+    mean = (s / n).float()
+    sq = ((adv - mean) ** 2).double().sum().view(1)
+    if _world() > 1:
+        dist.all_reduce(sq, op=dist.ReduceOp.SUM)
+    std = torch.sqrt(sq / n).float()
+    return (adv - mean) / std
+
+
+class Collector:
+    """The epoch loop body of train_PPO.train (train.py:332-548) for N envs at once: policy forward,
+    Philox inverse-CDF sampling, env lock-step, buffer write, episode/epoch cut logic, bootstrap values,
+    masked reset.  Nothing returns to the host inside the loop."""
+
+    def __init__(self, env: RadSearchVec, agents: Dict[int, VecAgentPPO], steps_per_epoch: int, steps_per_episode: int,
+                 global_critic_flag: bool = False, standardize: bool = True):
+        self.env, self.agents = env, agents
+        self.T, self.L = steps_per_epoch, steps_per_episode
+        self.N, self.A = env.num_envs, env.number_agents
+        self.team_reward = global_critic_flag
+        self.standardize = standardize
+        dev = env.device
+        self.buf = RolloutBuffer(self.T, self.N, self.A, _lib.RS_OBS_DIM, dev)
+        self.stat = DeviceWelford((self.N, self.A), dev)
+        self.steps_in_ep = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.ep_ret = torch.zeros(self.N, self.A, dtype=torch.float32, device=dev)
+        self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
+        self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
+        # epoch statistics (logger columns of train.py:605-627)
+        self.stats: Dict[str, torch.Tensor] = {}
+        self.obs = None
+        self.started = False
+
+    def _x(self, obs: torch.Tensor) -> torch.Tensor:
+        if not self.standardize:
+            return obs
+        x = obs.clone()
+        x[..., 0] = self.stat.standardize(obs[..., 0])
+        return x
+
+    def start(self) -> None:
+        """train.py:273-312: first reset + first Welford update."""
+        obs, *_ = self.env.reset()
+        self.obs = obs.clone()
+        self.stat.update(self.obs[..., 0])
+        self.started = True
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        if not self.started:
+            self.start()
+        env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
+        dev = env.device
+        done_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        oob_count = torch.zeros(N, A, dtype=torch.int32, device=dev)
+        ep_ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        ep_len_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        ep_cnt = torch.zeros((), dtype=torch.float64, device=dev)
+        for t in range(T):
+            x = self._x(self.obs)                                            # train.py:334-341
+            env.action_uniforms(self._u)
+            for a, ag in self.agents.items():                                # train.py:345-351
+                act, logp, v = ag.agent.act(x[:, a], self._u[:, a])
+                buf.act[t, :, a] = act
+                buf.logp[t, :, a] = logp
+                buf.val[t, :, a] = v
+                self._act8[:, a] = act.to(torch.int8)
+            buf.obs[t] = x
+            buf.source_tar[t, :, 0] = env.state("src_x")[0].float()
+            buf.source_tar[t, :, 1] = env.state("src_y")[0].float()
+            next_obs, rew, team, done, info = env.step(self._act8)           # train.py:361-363
+            r_used = team.unsqueeze(1).expand(N, A) if self.team_reward else rew
+            buf.rew[t] = r_used
+            self.ep_ret += r_used
+            self.steps_in_ep += 1
+            oob_count += info["out_of_bounds"].int()
+            terminal = done.any(dim=1)                                       # train.py:387-391
+            done_count += terminal.int()
+            timeout = self.steps_in_ep == L                                  # train.py:394-405
+            episode_over = terminal | timeout
+            epoch_ended = t == T - 1
+            cut = episode_over | epoch_ended
+            buf.cut[t] = cut.unsqueeze(1).to(torch.uint8).expand(N, A)
+            self.stat.update(next_obs[..., 0])                               # train.py:432-436
+            self.obs = next_obs.clone()
+            # bootstrap value on timeout / epoch cut, 0 on a pure terminal (train.py:462-487)
+            boot = timeout | epoch_ended
+            xb = self._x(self.obs)
+            for a, ag in self.agents.items():
+                vb = ag.agent.critic(xb[:, a]).squeeze(-1)
+                buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
+            # episode bookkeeping (train.py:494-501)
+            ep_ret_sum += (self.ep_ret[:, 0].double() * episode_over).sum()
+            ep_len_sum += (self.steps_in_ep.double() * episode_over).sum()
+            ep_cnt += episode_over.double().sum()
+            if epoch_ended:
+                env.set_epoch_end()                                          # train.py:482-484
+            self.stat.reset(cut)                                             # train.py:504-509
+            obs_r, *_ = env.reset(cut)                                       # train.py:530
+            self.obs = obs_r.clone()
+            self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
+            self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
+            self.stat.update(self.obs[..., 0], mask=cut)                     # train.py:542-548
+        buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return dict(DoneCount=done_count.sum(), OutOfBound=oob_count.sum(), EpRetSum=ep_ret_sum, EpLenSum=ep_len_sum,
+                    EpCount=ep_cnt)
+
+    def update(self) -> Dict[int, UpdateResult]:
+        """train.py:569-599: PPO update of every agent from the finished buffer."""
+        buf = self.buf
+        n_total = self.N * _world()
+        w = (self.buf.episode_weights() / n_total).reshape(-1)
+        out = {}
+        for a, ag in self.agents.items():
+            adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
+            X = buf.obs[:, :, a].reshape(-1, buf.obs.shape[-1])
+            out[a] = ag.update_agent(X, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
+                                     buf.logp[:, :, a].reshape(-1), w)
+        return out
