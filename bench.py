@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--collector", choices=["fused", "torch"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -126,7 +127,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     from radiation_ppo_amd.envs import RadSearchVec
-    from radiation_ppo_amd.ppo import Collector, VecAgentPPO
+    from radiation_ppo_amd.ppo import Collector, FusedCollector, VecAgentPPO
 
     N = args.envs_per_gpu
     torch.manual_seed(SEED % (2 ** 31))
@@ -134,7 +135,7 @@ def main():
                        env_id_base=rank * N, device=dev)
     agents = {0: VecAgentPPO(id=0, steps_per_epoch=T_EPOCH, steps_per_episode=L_EPISODE, alpha=0.1, device=dev)}
     agents[0].sync_params()
-    col = Collector(env, agents, T_EPOCH, L_EPISODE)
+    col = (FusedCollector if args.collector == "fused" else Collector)(env, agents, T_EPOCH, L_EPISODE)
 
     def barrier():
         if world > 1:
@@ -180,6 +181,7 @@ def main():
                                "480 steps/epoch, 120 steps/episode, walls enforced; step = 1 PPO iteration "
                                "(rollout + GAE + full update)",
                    "envs_per_gpu": N, "steps_per_epoch": T_EPOCH, "steps_per_episode": L_EPISODE,
+                   "collector": args.collector,
                    "parallelism": f"dp{world} (envs sharded, RCCL grad all-reduce)"},
         "ppo_iters_per_s": args.steps / dt,
         "collector_env_steps_per_s": args.steps * T_EPOCH * N / max(phases["collect"], 1e-9) * world,

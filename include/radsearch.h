@@ -129,6 +129,57 @@ int rs_error_flags(rs_handle* h, rs_stream_t stream, uint32_t* flags_out);
 int rs_gae(const float* rew, const float* val, const uint8_t* cut, const float* last_val, float* adv, float* ret,
            int32_t T, int32_t M, double gamma, double lam, rs_stream_t stream);
 
+/* ---- policy (FF_core.ActorCritic, NeuralNetworkCores/FF_core.py:42-129) ---------------------- */
+/* One 2x64 tanh MLP in torch layout: w1 [64,11], b1 [64], w2 [64,64], b2 [64], w3 [out,64], b3 [out]
+ * (row-major [out][in] float32, i.e. nn.Linear.weight / .bias of actor.0/.2/.4 or critic.0/.2/.4). */
+typedef struct rs_mlp_params {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+} rs_mlp_params;
+
+/* actor logits [M,8] (pre-softmax: actor.4 output) and critic value [M] for M observations x [M,11] on the
+ * matrix cores (v_mfma_f32_32x32x2_f32, exact f32).  Replaces ActorCritic.actor / .critic forward
+ * (FF_core.py:95-129).  Any of logits / value may be NULL. */
+int rs_policy_forward(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* x, int32_t M,
+                      float* logits, float* value, rs_stream_t stream);
+
+/* ---- fused on-device collector ------------------------------------------------------------------
+ * One launch = one epoch of the reference's collector loop (algos/multiagent/train.py:332-548) for all N
+ * envs of the handle (single agent, N % 64 == 0, geom_group_size == 1): per lock-step the MLP forward on the
+ * matrix cores, Philox inverse-CDF action sampling, the env step, the per-episode Welford standardisation
+ * (RADTEAM_core.py:188-277, train.py:334-341,432-436), episode/epoch cut rules (train.py:394-405), the
+ * bootstrap value (train.py:462-487), the masked reset (train.py:530) and the buffer row (PPOBuffer.store,
+ * ppo.py:339-381).  Nothing leaves HBM; the policy weights are read once per launch. */
+typedef struct rs_rollout_args {
+    int32_t steps_per_epoch;    /* T */
+    int32_t steps_per_episode;  /* L */
+    /* rollout buffer, time-major (device, caller-owned) */
+    float* obs;        /* [T,N,11] standardised observation fed to the networks */
+    int64_t* act;      /* [T,N] */
+    float* logp;       /* [T,N] */
+    float* val;        /* [T,N] */
+    float* rew;        /* [T,N] */
+    float* last_val;   /* [T,N] bootstrap value where cut != 0 */
+    uint8_t* cut;      /* [T,N] 1 = trajectory ends after this step */
+    float* source_tar; /* [T,N,2] */
+    /* collector state carried from epoch to epoch (device, caller-owned, [N]) */
+    float* cur_obs;    /* [N,11] raw observation of the current state (from rs_reset / previous launch) */
+    double* w_count;   /* Welford count, mean, M2, std */
+    double* w_mean;
+    double* w_sq;
+    double* w_std;
+    int32_t* steps_in_ep;
+    float* ep_ret;
+    /* per-env epoch statistics written by the launch ([N]) */
+    int32_t* done_count;
+    int32_t* oob_count;
+    double* ep_ret_sum;
+    double* ep_len_sum;
+    int32_t* ep_count;
+} rs_rollout_args;
+
+int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_rollout_args* args,
+               rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

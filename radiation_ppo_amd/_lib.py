@@ -29,6 +29,17 @@ class RsConfig(C.Structure):
     ]
 
 
+class RsMlpParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
+
+
+class RsRolloutArgs(C.Structure):
+    _fields_ = [("steps_per_epoch", C.c_int32), ("steps_per_episode", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("obs", "act", "logp", "val", "rew", "last_val", "cut", "source_tar", "cur_obs", "w_count",
+                                  "w_mean", "w_sq", "w_std", "steps_in_ep", "ep_ret", "done_count", "oob_count",
+                                  "ep_ret_sum", "ep_len_sum", "ep_count")]
+
+
 class RsInfo(C.Structure):
     _fields_ = [("out_of_bounds", C.c_void_p), ("out_of_bounds_count", C.c_void_p), ("blocked", C.c_void_p),
                 ("collision", C.c_void_p)]
@@ -50,6 +61,9 @@ SYMBOLS = [
                           C.POINTER(RsInfo), C.c_void_p]),
     ("rs_action_uniforms", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rs_error_flags", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("rs_policy_forward", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    ("rs_rollout", C.c_int, [C.c_void_p, C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.POINTER(RsRolloutArgs), C.c_void_p]),
     ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                          C.c_int32, C.c_double, C.c_double, C.c_void_p]),
 ]

@@ -540,3 +540,179 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
     P.tstep[n] = t + 1;
     if (err) P.err[n] |= err;
 }
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve-up of one wave.  geo: obstacle rectangles (per-lane or shared layout, see RsGeo);
+// tile: the wave's [64][A*11] observation rows (+ odd padding -> conflict-free row writes) that are
+// copied out as whole 256-byte rows; flags: which lanes produced a row.
+struct WaveLds {
+    int* geo;       // 28*64 ints
+    float* tile;    // 64 * S floats
+    int* flags;     // 64 ints
+};
+__device__ __forceinline__ int rs_tile_stride(int A) { int s = A * RS_OBS_DIM; return s | 1; }
+
+__device__ __forceinline__ void rs_load_geo(const RsParams& P, int n, bool active, int* lds_geo, RsGeo& g) {
+    const int lane = threadIdx.x & 63;
+    if (P.obstruction_count == 0) { g.r = lds_geo; g.stride = 0; g.off = 0; g.n = 0; return; }
+    const bool shared = (P.group % RS_WAVE) == 0;
+    if (shared) {
+        const int grp = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)) / P.group;   // wave-uniform
+        const int gi = min(grp, P.G - 1);
+        if (lane < RS_MAX_VERT) lds_geo[lane] = P.rect[(size_t)lane * P.G + gi];
+        g.r = lds_geo; g.stride = 1; g.off = 0; g.n = P.num_obs[gi];
+    } else {
+        const int gi = active ? n / P.group : 0;
+        const int no = active ? P.num_obs[gi] : 0;
+        for (int w = 0; w < 4 * no; ++w) lds_geo[w * RS_WAVE + lane] = P.rect[(size_t)w * P.G + gi];
+        g.r = lds_geo; g.stride = RS_WAVE; g.off = lane; g.n = no;
+    }
+}
+
+__device__ __forceinline__ void rs_copy_out(const RsParams& P, float* obs, const float* tile, const int* flags, int wave_env0) {
+    if (!obs) return;
+    const int lane = threadIdx.x & 63;
+    const int row = P.A * RS_OBS_DIM, S = rs_tile_stride(P.A);
+    const int total = RS_WAVE * row;
+    float* dst = obs + (size_t)wave_env0 * row;
+    for (int i = lane; i < total; i += RS_WAVE) {
+        int l = i / row, k = i - l * row;
+        if (flags[l]) dst[i] = tile[l * S + k];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// rectangles' boundaries share a point  <=>  isclose(boundary_distance(poly1, poly2), 0) (:988)
+__device__ __forceinline__ bool rs_rects_touch(int ax0, int ay0, int ax1, int ay1, int bx0, int by0, int bx1, int by1) {
+    bool overlap = ax0 <= bx1 && bx0 <= ax1 && ay0 <= by1 && by0 <= ay1;
+    bool a_in_b = bx0 < ax0 && ax1 < bx1 && by0 < ay0 && ay1 < by1;
+    bool b_in_a = ax0 < bx0 && bx1 < ax1 && ay0 < by0 && by1 < ay1;
+    return overlap && !a_in_b && !b_in_a;
+}
+
+// create_obs (:948-1011) into a per-lane LDS layout (stride 64) -- draws continue the caller's sequence
+__device__ __forceinline__ int rs_create_obs(const RsParams& P, RsDrawSeq& seq, int* lds_geo, int stride, int off) {
+    int num = P.obstruction_count;
+    if (num == -1) num = seq.integers(1, 6);
+    int ii = 0;
+    while (ii < num) {
+        int sx = seq.integers(P.sa_x0, P.obs_hi_x);
+        int sy = seq.integers(P.sa_y0, P.obs_hi_y);
+        int ex = seq.integers(P.oa_lo, P.oa_hi);
+        int ey = seq.integers(P.oa_lo, P.oa_hi);
+        bool touch = false;
+        for (int kk = 0; kk < ii && !touch; ++kk) {
+            int x0 = lds_geo[(kk * 4 + 0) * stride + off], y0 = lds_geo[(kk * 4 + 1) * stride + off];
+            int x1 = lds_geo[(kk * 4 + 2) * stride + off], y1 = lds_geo[(kk * 4 + 3) * stride + off];
+            touch = rs_rects_touch(x0, y0, x1, y1, sx, sy, sx + ex, sy + ey);
+        }
+        if (!touch) {
+            lds_geo[(ii * 4 + 0) * stride + off] = sx;
+            lds_geo[(ii * 4 + 1) * stride + off] = sy;
+            lds_geo[(ii * 4 + 2) * stride + off] = sx + ex;
+            lds_geo[(ii * 4 + 3) * stride + off] = sy + ey;
+            ii += 1;
+        }
+    }
+    return num;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// RadSearch.reset for env n (one lane): rad_search_env.py:730-797 with create_obs (per-env layouts),
+// sample_source_loc_pos :1013-1131, the source->vertex geodesic cache, and the initial step(None).
+// lds_adj / lds_d: per-wave scratch [28][64] (u32 / f64), only touched when HAS_OBS.
+template <bool HAS_OBS>
+__device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, int n, int* lds_geo, uint32_t* lds_adj,
+                                                  double* lds_d, float* obs_row, const RsOut& O) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, A = P.A;
+    const uint32_t episode = P.episode[n];
+    RsDrawSeq seq{P.seed, P.env_id_base + (uint32_t)n, episode, RS_STREAM_RESET, 0u};
+    // ---- per-env obstacle layout (geom_group_size == 1): resample when epoch_end is set (:744-762)
+    if (HAS_OBS && P.group == 1) {
+        g.r = lds_geo; g.stride = RS_WAVE; g.off = lane;
+        if (P.epoch_end[n]) {
+            int num = rs_create_obs(P, seq, lds_geo, RS_WAVE, lane);
+            P.num_obs[n] = num;
+            for (int w = 0; w < 4 * num; ++w) P.rect[(size_t)w * P.G + n] = lds_geo[w * RS_WAVE + lane];
+            g.n = num;
+        } else {
+            g.n = P.num_obs[n];
+            for (int w = 0; w < 4 * g.n; ++w) lds_geo[w * RS_WAVE + lane] = P.rect[(size_t)w * P.G + n];
+        }
+    }
+    P.epoch_end[n] = 0;
+    // ---- sample_source_loc_pos (:1013-1131); rand_point uses the x-range for both axes (:1033)
+    int srx = seq.integers(P.sa_x0, P.sa_x1), sry = seq.integers(P.sa_x0, P.sa_x1);
+    int dtx = seq.integers(P.sa_x0, P.sa_x1), dty = seq.integers(P.sa_x0, P.sa_x1);
+    for (;;) {
+        bool inside = false;
+        for (int o = 0; o < g.n && !inside; ++o) {
+            int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+            inside = (x0 <= dtx && dtx <= x1 && y0 <= dty && dty <= y1);
+        }
+        if (!inside) break;
+        dtx = seq.integers(P.sa_x0, P.sa_x1); dty = seq.integers(P.sa_x0, P.sa_x1);
+    }
+    int num_retry = 0;
+    for (;;) {
+        while (rs_dist_i(dtx, dty, srx, sry) < 1000.0) { srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1); }
+        bool resamp = false, inter = false;
+        for (int o = 0; o < g.n && !resamp; ++o) {
+            int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+            if (x0 <= srx && srx <= x1 && y0 <= sry && sry <= y1) resamp = true;
+            if (!resamp && rs_seg_rect_close(dtx, dty, srx, sry, x0, y0, x1, y1)) inter = true;
+        }
+        if (g.n == 0 || (num_retry > 20 && !resamp)) break;
+        else if (resamp || !inter) { srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1); num_retry += 1; }
+        else break;
+    }
+    // ---- geodesic distances source -> rectangle vertices (visibility graph relaxation)
+    const int V = HAS_OBS ? 4 * g.n : 0;
+    for (int v = 0; v < V; ++v) {
+        int vx, vy; g.vertex(v, vx, vy);
+        lds_d[v * RS_WAVE + lane] = rs_visible(g, srx, sry, vx, vy) ? rs_dist_i(srx, sry, vx, vy) : INFINITY;
+        uint32_t m = 0;
+        for (int u = 0; u < V; ++u) {
+            if (u == v) continue;
+            int ux, uy; g.vertex(u, ux, uy);
+            if (rs_visible(g, ux, uy, vx, vy)) m |= 1u << u;
+        }
+        lds_adj[v * RS_WAVE + lane] = m;
+    }
+    bool changed = V > 0;
+    while (changed) {
+        changed = false;
+        for (int v = 0; v < V; ++v) {
+            int vx, vy; g.vertex(v, vx, vy);
+            uint32_t m = lds_adj[v * RS_WAVE + lane];
+            double dv = lds_d[v * RS_WAVE + lane];
+            for (int u = 0; u < V; ++u) {
+                if (!(m >> u & 1u)) continue;
+                int ux, uy; g.vertex(u, ux, uy);
+                double c = lds_d[u * RS_WAVE + lane] + rs_dist_i(ux, uy, vx, vy);
+                if (c < dv) { dv = c; changed = true; }
+            }
+            lds_d[v * RS_WAVE + lane] = dv;
+        }
+    }
+    for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + lane];
+    double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
+    int intensity = seq.integers(1000000, 10000000);    // :778
+    int bkg = seq.integers(10, 51);                     // :779
+    // ---- state write (Agent.reset :292-301, reset :736-742, :771-776)
+    P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = intensity; P.bkg[n] = bkg;
+    P.done[n] = 0; P.iter_count[n] = 0; P.tstep[n] = 0;
+    for (int a = 0; a < A; ++a) {
+        size_t ia = (size_t)a * N + n;
+        P.ax[ia] = dtx; P.ay[ia] = dty; P.sp[ia] = prev; P.prev[ia] = prev; P.oobc[ia] = 0; P.aflags[ia] = 0;
+    }
+    // ---- initial observation: step(None) (:794-797)
+    RsOut o = O;
+    o.obs_row = obs_row;
+    P.episode[n] = episode + 1;       // draws of this episode are keyed by `episode`
+    rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
+    P.iter_count[n] = 0;
+}

@@ -56,6 +56,30 @@ class FFActorCritic(nn.Module):
         return logp, v, ent
 
 
+def mlp_params(seq: nn.Sequential) -> "_lib.RsMlpParams":
+    """C-ABI view (rs_mlp_params) of one FF_core Sequential: Linear layers at indices 0, 2, 4."""
+    t = [seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, seq[4].weight, seq[4].bias]
+    for x in t:
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
+    return _lib.RsMlpParams(*[x.data_ptr() for x in t])
+
+
+def policy_forward(ac: "FFActorCritic", x: torch.Tensor, want_logits: bool = True, want_value: bool = True):
+    """Actor logits [M,8] and critic value [M] on the matrix cores (rs_policy_forward)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == _lib.RS_OBS_DIM
+    M = x.numel() // _lib.RS_OBS_DIM
+    logits = torch.empty(M, 8, dtype=torch.float32, device=x.device) if want_logits else None
+    value = torch.empty(M, dtype=torch.float32, device=x.device) if want_value else None
+    pa, pc = mlp_params(ac.actor), mlp_params(ac.critic)
+    import ctypes as C
+    _lib.check(lib.rs_policy_forward(C.byref(pa), C.byref(pc), x.data_ptr(), M,
+                                     None if logits is None else logits.data_ptr(),
+                                     None if value is None else value.data_ptr(),
+                                     torch.cuda.current_stream(x.device).cuda_stream), "rs_policy_forward")
+    return logits, value
+
+
 class DeviceWelford:
     """StatisticStandardization (RADTEAM_core.py:188-277) for every (env, agent) at once, float64."""
 
@@ -346,14 +370,78 @@ class Collector:
                     EpCount=ep_cnt)
 
     def update(self) -> Dict[int, UpdateResult]:
-        """train.py:569-599: PPO update of every agent from the finished buffer."""
-        buf = self.buf
-        n_total = self.N * _world()
-        w = (self.buf.episode_weights() / n_total).reshape(-1)
-        out = {}
-        for a, ag in self.agents.items():
-            adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
-            X = buf.obs[:, :, a].reshape(-1, buf.obs.shape[-1])
-            out[a] = ag.update_agent(X, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
-                                     buf.logp[:, :, a].reshape(-1), w)
-        return out
+        return ppo_update_from_buffer(self)
+
+
+class FusedCollector:
+    """Same contract as Collector, but the whole epoch is ONE kernel launch (rs_rollout): MLP forward on
+    the matrix cores, sampling, env step, Welford, cut/bootstrap/reset logic and the buffer rows all happen
+    inside the kernel, 64 envs per wave.  Single agent, N % 64 == 0."""
+
+    def __init__(self, env: RadSearchVec, agents: Dict[int, VecAgentPPO], steps_per_epoch: int, steps_per_episode: int,
+                 global_critic_flag: bool = False, standardize: bool = True):
+        assert env.number_agents == 1 and len(agents) == 1 and env.num_envs % 64 == 0 and standardize
+        assert not global_critic_flag
+        self.env, self.agents = env, agents
+        self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, 1
+        dev = env.device
+        self.buf = RolloutBuffer(self.T, self.N, 1, _lib.RS_OBS_DIM, dev)
+        N = self.N
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.cur_obs = torch.zeros(N, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)
+        self.w_count, self.w_mean, self.w_sq = (torch.zeros(N, **f64) for _ in range(3))
+        self.w_std = torch.ones(N, **f64)
+        self.steps_in_ep = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ep_ret = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.done_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.oob_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ep_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.ep_ret_sum = torch.zeros(N, **f64)
+        self.ep_len_sum = torch.zeros(N, **f64)
+        b = self.buf
+        self._args = _lib.RsRolloutArgs(
+            self.T, self.L, b.obs.data_ptr(), b.act.data_ptr(), b.logp.data_ptr(), b.val.data_ptr(), b.rew.data_ptr(),
+            b.last_val.data_ptr(), b.cut.data_ptr(), b.source_tar.data_ptr(), self.cur_obs.data_ptr(),
+            self.w_count.data_ptr(), self.w_mean.data_ptr(), self.w_sq.data_ptr(), self.w_std.data_ptr(),
+            self.steps_in_ep.data_ptr(), self.ep_ret.data_ptr(), self.done_count.data_ptr(), self.oob_count.data_ptr(),
+            self.ep_ret_sum.data_ptr(), self.ep_len_sum.data_ptr(), self.ep_count.data_ptr())
+        self.started = False
+
+    def start(self) -> None:
+        """train.py:273-312: first reset + first Welford update."""
+        obs, *_ = self.env.reset()
+        self.cur_obs.copy_(obs[:, 0])
+        st = DeviceWelford((self.N,), self.env.device)
+        st.update(self.cur_obs[:, 0])
+        self.w_count.copy_(st.count); self.w_mean.copy_(st.mean); self.w_sq.copy_(st.sq); self.w_std.copy_(st.std)
+        self.started = True
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        import ctypes as C
+        if not self.started:
+            self.start()
+        ac = self.agents[0].agent
+        pa, pc = mlp_params(ac.actor), mlp_params(ac.critic)
+        _lib.check(self.env.lib.rs_rollout(self.env._h, C.byref(pa), C.byref(pc), C.byref(self._args), self.env._stream()),
+                   "rs_rollout")
+        self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return dict(DoneCount=self.done_count.sum(), OutOfBound=self.oob_count.sum(), EpRetSum=self.ep_ret_sum.sum(),
+                    EpLenSum=self.ep_len_sum.sum(), EpCount=self.ep_count.double().sum())
+
+    def update(self) -> Dict[int, UpdateResult]:
+        return ppo_update_from_buffer(self)
+
+
+def ppo_update_from_buffer(col) -> Dict[int, UpdateResult]:
+    """train.py:569-599: PPO update of every agent from the finished buffer of a collector."""
+    buf = col.buf
+    n_total = col.N * _world()
+    w = (buf.episode_weights() / n_total).reshape(-1)
+    out = {}
+    for a, ag in col.agents.items():
+        adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
+        X = buf.obs[:, :, a].reshape(-1, buf.obs.shape[-1])
+        out[a] = ag.update_agent(X, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
+                                 buf.logp[:, :, a].reshape(-1), w)
+    return out

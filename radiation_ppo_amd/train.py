@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 from .envs import RadSearch, RadSearchVec
-from .ppo import Collector, VecAgentPPO
+from .ppo import Collector, FusedCollector, VecAgentPPO
 
 # progress.txt columns of the reference (train.py:605-627) + throughput columns of this build
 COLUMNS = ["AgentID", "Epoch", "AverageVVals", "StdVVals", "MaxVVals", "MinVVals", "TotalEnvInteracts", "loss_policy",
@@ -103,8 +103,11 @@ class train_PPO:
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}
         for ag in self.agents.values():
             ag.sync_params()                                                   # train.py:248-256
-        self.collector = Collector(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
-                                   global_critic_flag=self.global_critic_flag)
+        fusable = (self.number_of_agents == 1 and self.vec.num_envs % 64 == 0 and self.vec.cfg.geom_group_size == 1
+                   and not self.global_critic_flag)
+        cls = FusedCollector if fusable else Collector      # one launch per epoch (rs_rollout) when the config allows
+        self.collector = cls(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
+                             global_critic_flag=self.global_critic_flag)
         self.start_time = time.time()
 
     def train(self) -> None:
