@@ -180,6 +180,33 @@ typedef struct rs_rollout_args {
 int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_rollout_args* args,
                rs_stream_t stream);
 
+/* ---- fused PPO loss + gradients ------------------------------------------------------------------
+ * One pass over the whole batch (M samples) computes the loss of AgentPPO.update_rada2c
+ * (algos/multiagent/ppo.py:1206-1225) in its batched form
+ *     L = -( sum_i w_i min(r_i A_i, clip(r_i, 1-c, 1+c) A_i)  -  vf * sum_i w_i (V_i - R_i)^2  +  alpha * sum_i w_i H_i )
+ * (w_i = 1 / (#ranks * #episodes of the sample's rank * length of its episode): the reference's mean over
+ * ranks of the mean over episodes of per-episode means), its statistics, and dL/dtheta for every parameter of
+ * the actor and the critic: forward, loss, backward and the weight-gradient GEMMs (contraction over samples,
+ * operands transposed through LDS) all on the matrix cores, gradients reduced deterministically.
+ * Replaces loss_pi.backward() (ppo.py:1253-1254) for the FF_core networks.
+ *   grads: float32 [10441] = actor {w1 704, b1 64, w2 4096, b2 64, w3 512, b3 8} then critic {704, 64, 4096, 64, 64, 1}
+ *   stats: float64 [5] = {approx_kl, entropy, clip fraction, value loss, total loss}   (weighted sums)
+ *   workspace: device scratch of rs_ppo_grad_workspace_bytes() bytes. */
+typedef struct rs_ppo_batch {
+    const float* x;        /* [M,11] */
+    const int64_t* act;    /* [M] */
+    const float* adv;      /* [M] normalised advantages */
+    const float* ret;      /* [M] */
+    const float* logp_old; /* [M] */
+    const float* w;        /* [M] */
+    int32_t M;
+    float clip_ratio, alpha, vf_coef;
+} rs_ppo_batch;
+
+size_t rs_ppo_grad_workspace_bytes(void);
+int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_ppo_batch* batch, float* grads,
+                double* stats, void* workspace, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,11 @@ class RsRolloutArgs(C.Structure):
                                   "ep_ret_sum", "ep_len_sum", "ep_count")]
 
 
+class RsPpoBatch(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("act", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p), ("logp_old", C.c_void_p),
+                ("w", C.c_void_p), ("M", C.c_int32), ("clip_ratio", C.c_float), ("alpha", C.c_float), ("vf_coef", C.c_float)]
+
+
 class RsInfo(C.Structure):
     _fields_ = [("out_of_bounds", C.c_void_p), ("out_of_bounds_count", C.c_void_p), ("blocked", C.c_void_p),
                 ("collision", C.c_void_p)]
@@ -64,6 +69,9 @@ SYMBOLS = [
     ("rs_policy_forward", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     ("rs_rollout", C.c_int, [C.c_void_p, C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.POINTER(RsRolloutArgs), C.c_void_p]),
+    ("rs_ppo_grad_workspace_bytes", C.c_size_t, []),
+    ("rs_ppo_grad", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.POINTER(RsPpoBatch), C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]),
     ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                          C.c_int32, C.c_double, C.c_double, C.c_void_p]),
 ]

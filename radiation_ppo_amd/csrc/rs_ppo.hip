@@ -221,6 +221,290 @@ __global__ void __launch_bounds__(64) rs_rollout_kernel(RsParams P, RsMlpParams 
     R.ep_ret_sum[n] = ep_ret_sum; R.ep_len_sum[n] = ep_len_sum;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K7: fused PPO loss + gradients for one FF_core network (NOUT = 8: actor, NOUT = 1: critic).
+//
+// 256-thread workgroups (4 waves, one per SIMD; ~450 registers per lane), one workgroup per CU, grid-stride
+// over groups of 64 samples.  Per group and wave: forward (rs_mlp.hpp), per-sample loss derivative on the
+// VALU, backward through the output layer on the VALU, then three weight-gradient GEMMs and one
+// activation-gradient GEMM on the matrix cores.  The weight-gradient GEMMs contract over SAMPLES, which sit
+// on the lanes in accumulator layout, so both operands are transposed through per-wave LDS tiles with row
+// stride 65 (conflict-free column writes AND row reads).  Gradient accumulators stay in registers for the
+// whole launch; each wave then writes one partial slab and rs_ppo_reduce_kernel sums the slabs in a fixed
+// order (bitwise reproducible, no float atomics).
+#define RS_TS 65                                  // LDS tile row stride (floats)
+
+__host__ __device__ constexpr int rs_net_params(int nout) { return 64 * 11 + 64 + 64 * 64 + 64 + nout * 64 + nout; }
+__host__ __device__ constexpr int rs_grad_lds_floats(int nout) { return rs_mlp_lds_floats(nout) + 2 * 2 * 16 * 64 + 4 * (64 + 32 + 12) * RS_TS; }
+
+__device__ __forceinline__ void rs_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stage an accumulator-layout half (32 units x 64 samples: v[jt][r]) as T[unit_local][sample]
+__device__ __forceinline__ void rs_stage_half(float* T, const f32x16 (&v)[2], int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[rs_kappa(r, h) * RS_TS + 32 * jt + j] = v[jt][r];
+}
+
+template <int NOUT>
+__global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs_ppo_batch B, float* __restrict__ partial,
+                                                             double* __restrict__ stat_partial) {
+    extern __shared__ __align__(16) float smem_f[];
+    RsMlpLds<NOUT> W;
+    W.carve(smem_f);
+    float* w2tf = smem_f + rs_mlp_lds_floats(NOUT);                    // [2 it][2 kt][16 r][64]: W2[32kt + kappa][32it + (l&31)]
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    float* Qt = w2tf + 2 * 2 * 16 * 64 + wid * (64 + 32 + 12) * RS_TS;   // [64][65]
+    float* Pt = Qt + 64 * RS_TS;                                        // [32][65]
+    float* St = Pt + 32 * RS_TS;                                        // [12][65]
+    W.fill(prm);
+    for (int i = threadIdx.x; i < 2 * 2 * 16 * 64; i += blockDim.x) {
+        int l = i & 63, r = (i >> 6) & 15, kt = (i >> 10) & 1, it = i >> 11;
+        w2tf[i] = prm.w2[(32 * kt + rs_kappa(r, l >> 5)) * RS_HID + 32 * it + (l & 31)];
+    }
+    __syncthreads();
+
+    const int M = B.M;
+    const int groups = (M + 63) / 64;
+    const int wave_g = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+
+    f32x16 acc2[2][2], acc1[2], acc3[2], db2[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc2[a][0][r] = 0.f; acc2[a][1][r] = 0.f; acc1[a][r] = 0.f; acc3[a][r] = 0.f; db2[a][r] = 0.f; }
+    }
+    float db3[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) db3[o] = 0.f;
+    double st_kl = 0.0, st_ent = 0.0, st_cf = 0.0, st_vl = 0.0, st_surr = 0.0;
+
+    for (int gi = wave_g; gi < groups; gi += n_waves) {
+        const int m = gi * 64 + lane;
+        const bool valid = m < M;
+        const int mm = valid ? m : M - 1;
+        float xo[RS_IN_PAD], xp[RS_IN_PAD];
+#pragma unroll
+        for (int k = 0; k < RS_IN; ++k) xo[k] = B.x[(size_t)mm * RS_IN + k];
+        xo[11] = 0.0f;
+        rs_exchange_x(xo, xp);
+        const float wi = valid ? B.w[mm] : 0.0f;
+
+        RsHidden H1, H2;
+        rs_mlp_layer1<NOUT>(W, xo, xp, H1);
+        rs_mlp_layer2<NOUT>(W, H1, H2);
+        float out[NOUT];
+        rs_mlp_out<NOUT>(W, H2, out);
+
+        // ---- per-sample loss derivative wrt the network outputs (own sample)
+        float dz[NOUT];
+        if (NOUT == 8) {
+            const int a = (int)B.act[mm];
+            const float adv = B.adv[mm], lpo = B.logp_old[mm];
+            float mx = out[0];
+#pragma unroll
+            for (int j = 1; j < NOUT; ++j) mx = fmaxf(mx, out[j]);
+            float se = 0.f;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) se += expf(out[j] - mx);
+            const float lse = logf(se);
+            float lp[NOUT], pj[NOUT], ent = 0.f, logp = 0.f;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                lp[j] = (out[j] - mx) - lse;
+                pj[j] = expf(lp[j]);
+                ent -= pj[j] * lp[j];
+                logp = (a == j) ? lp[j] : logp;
+            }
+            const float ratio = expf(logp - lpo);
+            const float lo = 1.0f - B.clip_ratio, hi = 1.0f + B.clip_ratio;
+            const float clipped = fminf(fmaxf(ratio, lo), hi);
+            const float s1 = ratio * adv, s2 = clipped * adv;
+            const float surr = fminf(s1, s2);
+            const bool inside = ratio >= lo && ratio <= hi;
+            const float dr = (inside || s1 < s2) ? adv : 0.0f;           // d min(r A, clip(r) A) / dr
+            const float g_lp = -wi * dr * ratio;                          // d(-w surr)/d logp
+            const float g_h = -B.alpha * wi;                              // d(-alpha w H)/dH
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j)
+                dz[j] = g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j]) + g_h * (-pj[j] * (lp[j] + ent));
+            st_kl += (double)(wi * (lpo - logp));
+            st_ent += (double)(wi * ent);
+            st_cf += (double)(wi * ((ratio > hi || ratio < lo) ? 1.0f : 0.0f));
+            st_surr += (double)(wi * surr);
+        } else {
+            const float diff = out[0] - B.ret[mm];
+            dz[0] = 2.0f * B.vf_coef * wi * diff;                          // d(vf w (V-R)^2)/dV
+            st_vl += (double)(wi * diff * diff);
+        }
+        float dzp[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) { dzp[o] = __shfl_xor(dz[o], 32); db3[o] += dz[o]; }
+
+        // ---- dW3 += dz . h2^T   (A = dz tile from LDS, B = h2^T tile from LDS)
+        rs_stage_half(Qt, H2.v[0], lane);
+        rs_stage_half(Qt + 32 * RS_TS, H2.v[1], lane);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) St[o * RS_TS + lane] = dz[o];
+        rs_wave_sync();
+#pragma unroll 4
+        for (int s = 0; s < 32; ++s) {
+            const float a = (c < NOUT) ? St[c * RS_TS + 2 * s + h] : 0.0f;
+            const float b0 = Qt[c * RS_TS + 2 * s + h], b1 = Qt[(32 + c) * RS_TS + 2 * s + h];
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc3[0], 0, 0, 0);
+            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc3[1], 0, 0, 0);
+        }
+        // ---- backward through the output layer (VALU): dh2, then dpre2 = dh2 * (1 - h2^2) in place of H2
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float wv = W.w3h[(h * NOUT + o) * 32 + kt * 16 + r];
+                    const float z0 = h ? dzp[o] : dz[o];       // sample tile jt = 0 is owned by lanes < 32
+                    const float z1 = h ? dz[o] : dzp[o];
+                    d0 = fmaf(wv, z0, d0);
+                    d1 = fmaf(wv, z1, d1);
+                }
+                const float h20 = H2.v[kt][0][r], h21 = H2.v[kt][1][r];
+                H2.v[kt][0][r] = d0 * (1.0f - h20 * h20);
+                H2.v[kt][1][r] = d1 * (1.0f - h21 * h21);
+            }
+        // ---- dW2 += dpre2 . h1^T ; db2 += dpre2
+        rs_wave_sync();
+        rs_stage_half(Qt, H1.v[0], lane);
+        rs_stage_half(Qt + 32 * RS_TS, H1.v[1], lane);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            rs_wave_sync();
+            rs_stage_half(Pt, H2.v[it], lane);
+            rs_wave_sync();
+#pragma unroll 4
+            for (int s = 0; s < 32; ++s) {
+                const float a = Pt[c * RS_TS + 2 * s + h];
+                const float b0 = Qt[c * RS_TS + 2 * s + h], b1 = Qt[(32 + c) * RS_TS + 2 * s + h];
+                acc2[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc2[it][0], 0, 0, 0);
+                acc2[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc2[it][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) db2[it][r] += H2.v[it][0][r] + H2.v[it][1][r];
+        }
+        // ---- dh1 = W2^T . dpre2 (accumulator layout in/out), dpre1 = dh1 * (1 - h1^2) in place of H1
+        RsHidden D1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { D1.v[it][0][r] = 0.f; D1.v[it][1][r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const float a = w2tf[((it * 2 + kt) * 16 + r) * 64 + lane];
+                    D1.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H2.v[kt][0][r], D1.v[it][0], 0, 0, 0);
+                    D1.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H2.v[kt][1][r], D1.v[it][1], 0, 0, 0);
+                }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = H1.v[it][jt][r];
+                    D1.v[it][jt][r] = D1.v[it][jt][r] * (1.0f - hv * hv);
+                }
+        // ---- dW1 += dpre1 . x^T with x[11] := 1, so column 11 of the product is db1
+        rs_wave_sync();
+#pragma unroll
+        for (int k = 0; k < RS_IN; ++k) St[k * RS_TS + lane] = xo[k];
+        St[11 * RS_TS + lane] = 1.0f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            rs_wave_sync();
+            rs_stage_half(Pt, D1.v[it], lane);
+            rs_wave_sync();
+#pragma unroll 4
+            for (int s = 0; s < 32; ++s) {
+                const float a = Pt[c * RS_TS + 2 * s + h];
+                const float b = (c < RS_IN_PAD) ? St[c * RS_TS + 2 * s + h] : 0.0f;
+                acc1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1[it], 0, 0, 0);
+            }
+        }
+        rs_wave_sync();
+    }
+
+    // ---- one partial slab per wave, in the parameter order {w1, b1, w2, b2, w3, b3}
+    float* out = partial + (size_t)wave_g * rs_net_params(NOUT);
+    float* g_w1 = out, *g_b1 = g_w1 + 64 * 11, *g_w2 = g_b1 + 64, *g_b2 = g_w2 + 64 * 64, *g_w3 = g_b2 + 64, *g_b3 = g_w3 + NOUT * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * it + rs_kappa(r, h);
+            g_w2[row * 64 + c] = acc2[it][0][r];
+            g_w2[row * 64 + 32 + c] = acc2[it][1][r];
+            if (c < RS_IN) g_w1[row * RS_IN + c] = acc1[it][r];
+            if (c == RS_IN) g_b1[row] = acc1[it][r];
+            // db2: sum the 32 lanes that share this (r, h)
+            float v = db2[it][r];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            if (c == 0) g_b2[row] = v;
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = rs_kappa(r, h);
+        if (o < NOUT) { g_w3[o * 64 + c] = acc3[0][r]; g_w3[o * 64 + 32 + c] = acc3[1][r]; }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float v = db3[o];
+        v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        if (lane == 0) g_b3[o] = v;
+    }
+    double sv[5] = {st_kl, st_ent, st_cf, st_vl, st_surr};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double v = sv[q];
+        v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        if (lane == 0) stat_partial[(size_t)wave_g * 5 + q] = v;
+    }
+}
+
+// deterministic reduction of the per-wave slabs: thread p sums parameter p over the waves in order
+__global__ void __launch_bounds__(256) rs_ppo_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
+                                                            const double* __restrict__ sa, const double* __restrict__ sc, int n_waves,
+                                                            float* __restrict__ grads, double* __restrict__ stats, float alpha, float vf) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NA = rs_net_params(8), NC = rs_net_params(1);
+    if (p < NA + NC) {
+        const float* src = (p < NA) ? pa + p : pc + (p - NA);
+        const int stride = (p < NA) ? NA : NC;
+        float acc = 0.0f;
+        for (int w = 0; w < n_waves; ++w) acc += src[(size_t)w * stride];
+        grads[p] = acc;
+    }
+    if (p == 0) {
+        double t[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < n_waves; ++w) {
+            t[0] += sa[w * 5 + 0]; t[1] += sa[w * 5 + 1]; t[2] += sa[w * 5 + 2]; t[4] += sa[w * 5 + 4];
+            t[3] += sc[w * 5 + 3];
+        }
+        stats[0] = t[0]; stats[1] = t[1]; stats[2] = t[2]; stats[3] = t[3];
+        stats[4] = -(t[4] - (double)vf * t[3] + (double)alpha * t[1]);       // ppo.py:1221-1225
+    }
+}
+
+#define RS_GRAD_BLOCKS 256
+
 extern "C" {
 
 int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_rollout_args* args,
@@ -237,6 +521,37 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (has_obs) hipLaunchKernelGGL(rs_rollout_kernel<true>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
     else hipLaunchKernelGGL(rs_rollout_kernel<false>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+size_t rs_ppo_grad_workspace_bytes(void) {
+    const size_t waves = RS_GRAD_BLOCKS * 4;
+    return waves * (size_t)(rs_net_params(8) + rs_net_params(1)) * sizeof(float) + 2 * waves * 5 * sizeof(double) + 512;
+}
+
+int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_ppo_batch* batch, float* grads,
+                double* stats, void* workspace, rs_stream_t stream) {
+    if (!actor || !critic || !batch || !grads || !stats || !workspace || batch->M < 1) return RS_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int waves = RS_GRAD_BLOCKS * 4;
+    float* pa = static_cast<float*>(workspace);
+    float* pc = pa + (size_t)waves * rs_net_params(8);
+    double* sa = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pc + (size_t)waves * rs_net_params(1)) + 255) & ~uintptr_t(255));
+    double* sc = sa + (size_t)waves * 5;
+    static bool attr_set = false;
+    const size_t lds_a = sizeof(float) * (size_t)rs_grad_lds_floats(8), lds_c = sizeof(float) * (size_t)rs_grad_lds_floats(1);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
+            return RS_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rs_ppo_grad_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_a, s, to_dev(actor), *batch, pa, sa);
+    hipLaunchKernelGGL(rs_ppo_grad_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_c, s, to_dev(critic), *batch, pc, sc);
+    const int np = rs_net_params(8) + rs_net_params(1);
+    hipLaunchKernelGGL(rs_ppo_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, s, pa, pc, sa, sc, waves, grads, stats,
+                       batch->alpha, batch->vf_coef);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

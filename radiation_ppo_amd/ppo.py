@@ -80,6 +80,49 @@ def policy_forward(ac: "FFActorCritic", x: torch.Tensor, want_logits: bool = Tru
     return logits, value
 
 
+N_PARAMS = 10441          # FF_core actor 5448 + critic 4993
+
+
+class FusedPPOGrad:
+    """rs_ppo_grad: loss statistics and all parameter gradients of the FF_core actor+critic in one pass over
+    the batch on the matrix cores (replaces loss.backward(), ppo.py:1253-1254)."""
+
+    def __init__(self, ac: "FFActorCritic"):
+        import ctypes as C
+        self.lib = _lib.load()
+        self.ac = ac
+        dev = next(ac.parameters()).device
+        self.grads = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(5, dtype=torch.float64, device=dev)
+        self.ws = torch.empty(self.lib.rs_ppo_grad_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
+        self._ws_ptr = self.ws.data_ptr() + (-self.ws.data_ptr()) % 256
+        # views of the flat gradient in the parameter order of the C ABI
+        order = [ac.actor[0].weight, ac.actor[0].bias, ac.actor[2].weight, ac.actor[2].bias, ac.actor[4].weight, ac.actor[4].bias,
+                 ac.critic[0].weight, ac.critic[0].bias, ac.critic[2].weight, ac.critic[2].bias, ac.critic[4].weight, ac.critic[4].bias]
+        self.views = []
+        o = 0
+        for p in order:
+            self.views.append((p, self.grads[o:o + p.numel()].view_as(p)))
+            o += p.numel()
+        assert o == N_PARAMS
+
+    def __call__(self, X, act, adv, ret, logp_old, w, clip_ratio: float, alpha: float, vf_coef: float = 0.01):
+        import ctypes as C
+        for t in (X, adv, ret, logp_old, w):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert act.dtype == torch.int64 and act.is_contiguous()
+        b = _lib.RsPpoBatch(X.data_ptr(), act.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp_old.data_ptr(), w.data_ptr(),
+                            X.shape[0], clip_ratio, alpha, vf_coef)
+        pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
+        _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
+                                        self._ws_ptr, torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
+        return self.stats, self.grads
+
+    def assign_grads(self) -> None:
+        for p, g in self.views:
+            p.grad = g
+
+
 class DeviceWelford:
     """StatisticStandardization (RADTEAM_core.py:188-277) for every (env, agent) at once, float64."""
 
@@ -187,6 +230,8 @@ class VecAgentPPO:
         self.pi_optimizer = torch.optim.Adam(self.agent.parameters(), lr=actor_learning_rate)
         self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)   # ppo.py:205-207
         self._flat_grad: Optional[torch.Tensor] = None
+        self.fused_update = True            # rs_ppo_grad on the GPU; the autograd path remains for CPU / A-B checks
+        self._fused: Optional[FusedPPOGrad] = None
 
     def sync_params(self) -> None:
         """mpi_pytorch.sync_params (mpi_pytorch.py:43-49): one RCCL broadcast of the flattened parameters."""
@@ -219,6 +264,8 @@ class VecAgentPPO:
         kl_reached = False
         last = None
         thr = 1.5 * self.target_kl
+        if self.fused_update and X.is_cuda:
+            return self._update_agent_fused(X, act, adv, ret, logp_old, w)
         while not kl_reached and kk < self.train_pi_iters:
             logp, v, ent = self.agent.evaluate(X, act)
             ratio = torch.exp(logp - logp_old)
@@ -244,6 +291,28 @@ class VecAgentPPO:
                 kl_reached = True
             kk += 1
         self.pi_scheduler.step()                                       # ppo.py:799
+        return UpdateResult(stop_iteration=kk, loss_policy=last[4], loss_critic=last[3], loss_predictor=0.0,
+                            kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
+
+    def _update_agent_fused(self, X, act, adv, ret, logp_old, w) -> UpdateResult:
+        """Same control flow as update_agent, with rs_ppo_grad in place of the autograd forward/backward."""
+        if self._fused is None:
+            self._fused = FusedPPOGrad(self.agent)
+        kk, kl_reached, last, thr = 0, False, None, 1.5 * self.target_kl
+        while not kl_reached and kk < self.train_pi_iters:
+            stats, grads = self._fused(X, act, adv, ret, logp_old, w, self.clip_ratio, self.alpha)
+            if _world() > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)           # mpi_avg(kl) (ppo.py:1250)
+            last = stats.tolist()                                        # the early-stop decision needs the host
+            if last[0] < thr:
+                if _world() > 1:
+                    dist.all_reduce(grads, op=dist.ReduceOp.SUM)       # mpi_avg_grads (ppo.py:1256): one flat bucket
+                self._fused.assign_grads()
+                self.pi_optimizer.step()
+            else:
+                kl_reached = True
+            kk += 1
+        self.pi_scheduler.step()
         return UpdateResult(stop_iteration=kk, loss_policy=last[4], loss_critic=last[3], loss_predictor=0.0,
                             kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
 

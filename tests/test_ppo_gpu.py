@@ -253,3 +253,58 @@ def test_fused_collector_replays_through_oracle(obst):
     col.collect()
     res = col.update()[0]
     assert 1 <= res.stop_iteration <= 40 and np.isfinite(res.loss_policy)
+
+
+def _torch_loss_and_grads(ac, X, act, adv, ret, lpo, w, clip, alpha, vf=0.01):
+    for p in ac.parameters():
+        p.grad = None
+    logp, v, ent = ac.evaluate(X, act)
+    ratio = torch.exp(logp - lpo)
+    surr = torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv)
+    vl = (w * (v - ret) ** 2).sum()
+    loss = -((w * surr).sum() - vf * vl + alpha * (w * ent).sum())
+    loss.backward()
+    clipped = (ratio > 1 + clip) | (ratio < 1 - clip)
+    stats = [(w * (lpo - logp)).sum().item(), (w * ent).sum().item(), (w * clipped.float()).sum().item(), vl.item(), loss.item()]
+    order = [ac.actor[0].weight, ac.actor[0].bias, ac.actor[2].weight, ac.actor[2].bias, ac.actor[4].weight, ac.actor[4].bias,
+             ac.critic[0].weight, ac.critic[0].bias, ac.critic[2].weight, ac.critic[2].bias, ac.critic[4].weight, ac.critic[4].bias]
+    return stats, torch.cat([p.grad.reshape(-1) for p in order])
+
+
+@pytest.mark.parametrize("M", [64, 1000, 4096 * 5 + 3])
+def test_fused_ppo_grad_matches_autograd(M):
+    """rs_ppo_grad (forward + loss + backward + weight-gradient GEMMs on the matrix cores) against torch
+    autograd on the same batch: loss statistics and every parameter gradient, fp32 tolerance."""
+    from radiation_ppo_amd.ppo import FFActorCritic, FusedPPOGrad
+    torch.manual_seed(M)
+    ac = FFActorCritic().cuda()
+    with torch.no_grad():
+        for p in ac.parameters():
+            p.copy_(torch.randn_like(p) * 0.25)
+    X = torch.randn(M, 11, device="cuda")
+    act = torch.randint(0, 8, (M,), device="cuda")
+    adv = torch.randn(M, device="cuda")
+    ret = torch.randn(M, device="cuda")
+    with torch.no_grad():
+        lpo = ac.evaluate(X, act)[0] + 0.3 * torch.randn(M, device="cuda")     # ratios on both sides of the clip
+    w = torch.rand(M, device="cuda")
+    w = w / w.sum()
+    ref_stats, ref_g = _torch_loss_and_grads(ac, X, act, adv, ret, lpo, w, 0.2, 0.1)
+    fused = FusedPPOGrad(ac)
+    stats, g = fused(X, act, adv, ret, lpo, w, 0.2, 0.1)
+    stats = stats.tolist()
+    for a, b in zip(stats, ref_stats):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (stats, ref_stats)
+    scale = ref_g.abs().max().item()
+    err = (g - ref_g).abs().max().item()
+    assert err <= 2e-4 * scale, (err, scale)
+    # per-tensor check (catches a transposed or mis-ordered block that a global max could hide)
+    o = 0
+    for name, n in (("a.w1", 704), ("a.b1", 64), ("a.w2", 4096), ("a.b2", 64), ("a.w3", 512), ("a.b3", 8),
+                    ("c.w1", 704), ("c.b1", 64), ("c.w2", 4096), ("c.b2", 64), ("c.w3", 64), ("c.b3", 1)):
+        r, f = ref_g[o:o + n], g[o:o + n]
+        assert (f - r).abs().max().item() <= 3e-4 * max(r.abs().max().item(), 1e-6) + 1e-7, name
+        o += n
+    # bitwise reproducible (slab reduction, no float atomics)
+    stats2, g2 = fused(X, act, adv, ret, lpo, w, 0.2, 0.1)
+    assert torch.equal(g2, g.clone()) or torch.equal(g2, g)
