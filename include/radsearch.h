@@ -204,8 +204,27 @@ typedef struct rs_ppo_batch {
 } rs_ppo_batch;
 
 size_t rs_ppo_grad_workspace_bytes(void);
+/* stop_flag (device int32, may be NULL): when non-zero at launch the call is a no-op (early stop already hit). */
 int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_ppo_batch* batch, float* grads,
-                double* stats, void* workspace, rs_stream_t stream);
+                double* stats, void* workspace, const int32_t* stop_flag, rs_stream_t stream);
+
+/* Device-side state of one update_agent call (algos/multiagent/ppo.py:789-796): lives in HBM so the whole
+ * "<= train_pi_iters Adam steps with KL early stop" loop can be enqueued without a host round trip. */
+typedef struct rs_update_state {
+    int32_t adam_step;   /* optimiser step count (bias correction), persists across epochs            */
+    int32_t stopped;     /* 1 once approx_kl >= threshold was seen in this update (reset by the host)  */
+    int32_t iters;       /* loss evaluations done in this update == the reference's `kk`               */
+    int32_t pad;
+    double last_stats[5]; /* stats of the last evaluated iteration {kl, entropy, clipfrac, vloss, loss} */
+} rs_update_state;
+
+/* One iteration of the reference's early-stopped loop (ppo.py:1250-1261) after rs_ppo_grad:
+ *   if state->stopped: nothing.  else iters += 1, last_stats = stats;
+ *   if stats[0] (approx_kl, already reduced over ranks) < kl_threshold: Adam step (torch.optim.Adam
+ *   semantics, betas (0.9, 0.999), eps 1e-8) on all 12 tensors with `grads`; else stopped = 1.
+ * actor/critic point at the LIVE parameter tensors (updated in place); m, v: float32 [10441]. */
+int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
+                 const double* stats, rs_update_state* state, float lr, float kl_threshold, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

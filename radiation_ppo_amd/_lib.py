@@ -71,7 +71,9 @@ SYMBOLS = [
     ("rs_rollout", C.c_int, [C.c_void_p, C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.POINTER(RsRolloutArgs), C.c_void_p]),
     ("rs_ppo_grad_workspace_bytes", C.c_size_t, []),
     ("rs_ppo_grad", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.POINTER(RsPpoBatch), C.c_void_p, C.c_void_p,
-                              C.c_void_p, C.c_void_p]),
+                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rs_adam_step", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                          C.c_int32, C.c_double, C.c_double, C.c_void_p]),
 ]

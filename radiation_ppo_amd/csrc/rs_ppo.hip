@@ -254,8 +254,9 @@ __device__ __forceinline__ void rs_stage_half(float* T, const f32x16 (&v)[2], in
 
 template <int NOUT>
 __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs_ppo_batch B, float* __restrict__ partial,
-                                                             double* __restrict__ stat_partial) {
+                                                             double* __restrict__ stat_partial, const int* __restrict__ stop) {
     extern __shared__ __align__(16) float smem_f[];
+    if (stop && *stop) return;                      // early stop already hit: this iteration is a no-op
     RsMlpLds<NOUT> W;
     W.carve(smem_f);
     float* w2tf = smem_f + rs_mlp_lds_floats(NOUT);                    // [2 it][2 kt][16 r][64]: W2[32kt + kappa][32it + (l&31)]
@@ -479,31 +480,85 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
     }
 }
 
-// deterministic reduction of the per-wave slabs: thread p sums parameter p over the waves in order
-__global__ void __launch_bounds__(256) rs_ppo_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
-                                                            const double* __restrict__ sa, const double* __restrict__ sc, int n_waves,
-                                                            float* __restrict__ grads, double* __restrict__ stats, float alpha, float vf) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// deterministic reduction of the per-wave slabs: a workgroup owns 64 consecutive parameters; 16 thread
+// groups each sum a fixed 1/16 of the slabs in order (coalesced 256-byte rows), then the 16 partial sums are
+// added in a fixed order through LDS.  Same order every launch -> bitwise reproducible gradients.
+__global__ void __launch_bounds__(1024) rs_ppo_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
+                                                             const double* __restrict__ sa, const double* __restrict__ sc, int n_waves,
+                                                             float* __restrict__ grads, double* __restrict__ stats, float alpha, float vf,
+                                                             const int* __restrict__ stop) {
+    __shared__ float part[16][64];
+    if (stop && *stop) return;
+    __shared__ double spart[5][64];
     constexpr int NA = rs_net_params(8), NC = rs_net_params(1);
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + col;
+    float acc = 0.0f;
     if (p < NA + NC) {
         const float* src = (p < NA) ? pa + p : pc + (p - NA);
         const int stride = (p < NA) ? NA : NC;
-        float acc = 0.0f;
-        for (int w = 0; w < n_waves; ++w) acc += src[(size_t)w * stride];
-        grads[p] = acc;
+        const int per = (n_waves + 15) / 16;
+        const int w0 = grp * per, w1 = min(w0 + per, n_waves);
+        for (int w = w0; w < w1; ++w) acc += src[(size_t)w * stride];
     }
-    if (p == 0) {
+    part[grp][col] = acc;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // statistics: 64 threads each own a fixed subset of the waves, then a fixed-order sum
         double t[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < n_waves; ++w) {
+        for (int w = threadIdx.x; w < n_waves; w += 64) {
             t[0] += sa[w * 5 + 0]; t[1] += sa[w * 5 + 1]; t[2] += sa[w * 5 + 2]; t[4] += sa[w * 5 + 4];
             t[3] += sc[w * 5 + 3];
         }
+        for (int q = 0; q < 5; ++q) spart[q][threadIdx.x] = t[q];
+    }
+    __syncthreads();
+    if (grp == 0 && p < NA + NC) {
+        float v = part[0][col];
+        for (int g2 = 1; g2 < 16; ++g2) v += part[g2][col];
+        grads[p] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t[5];
+        for (int q = 0; q < 5; ++q) { double v = 0; for (int i = 0; i < 64; ++i) v += spart[q][i]; t[q] = v; }
         stats[0] = t[0]; stats[1] = t[1]; stats[2] = t[2]; stats[3] = t[3];
         stats[4] = -(t[4] - (double)vf * t[3] + (double)alpha * t[1]);       // ppo.py:1221-1225
     }
 }
 
 #define RS_GRAD_BLOCKS 256
+
+// Adam (torch.optim.Adam semantics) + the KL early-stop decision, on the device.
+struct RsParamSeg { float* p[12]; int off[13]; };
+
+__global__ void __launch_bounds__(256) rs_adam_apply_kernel(RsParamSeg S, const float* __restrict__ grads, float* __restrict__ m,
+                                                            float* __restrict__ v, const double* __restrict__ stats,
+                                                            const rs_update_state* __restrict__ st, float lr, float thr) {
+    if (st->stopped) return;
+    if (!(stats[0] < (double)thr)) return;                       // kl >= 1.5 * target_kl: no step (ppo.py:1252-1261)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S.off[12]) return;
+    int seg = 0;
+#pragma unroll
+    for (int k = 1; k < 12; ++k) seg += (i >= S.off[k]) ? 1 : 0;
+    float* p = S.p[seg] + (i - S.off[seg]);
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const int step = st->adam_step + 1;
+    const float g = grads[i];
+    const float mi = m[i] + (g - m[i]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    const float step_size = lr / bc1;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    *p = *p - step_size * (mi / denom);
+}
+
+__global__ void rs_adam_commit_kernel(const double* __restrict__ stats, rs_update_state* st, float thr) {
+    if (st->stopped) return;
+    st->iters += 1;
+    for (int q = 0; q < 5; ++q) st->last_stats[q] = stats[q];
+    if (stats[0] < (double)thr) st->adam_step += 1; else st->stopped = 1;
+}
 
 extern "C" {
 
@@ -529,8 +584,24 @@ size_t rs_ppo_grad_workspace_bytes(void) {
     return waves * (size_t)(rs_net_params(8) + rs_net_params(1)) * sizeof(float) + 2 * waves * 5 * sizeof(double) + 512;
 }
 
+int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
+                 const double* stats, rs_update_state* state, float lr, float kl_threshold, rs_stream_t stream) {
+    if (!actor || !critic || !grads || !m || !v || !stats || !state) return RS_ERR_INVALID_ARG;
+    RsParamSeg S;
+    const float* ptrs[12] = {actor->w1, actor->b1, actor->w2, actor->b2, actor->w3, actor->b3,
+                             critic->w1, critic->b1, critic->w2, critic->b2, critic->w3, critic->b3};
+    const int sizes[12] = {704, 64, 4096, 64, 512, 8, 704, 64, 4096, 64, 64, 1};
+    int o = 0;
+    for (int k = 0; k < 12; ++k) { S.p[k] = const_cast<float*>(ptrs[k]); S.off[k] = o; o += sizes[k]; }
+    S.off[12] = o;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rs_adam_apply_kernel, dim3((o + 255) / 256), dim3(256), 0, s, S, grads, m, v, stats, state, lr, kl_threshold);
+    hipLaunchKernelGGL(rs_adam_commit_kernel, dim3(1), dim3(1), 0, s, stats, state, kl_threshold);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
 int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_ppo_batch* batch, float* grads,
-                double* stats, void* workspace, rs_stream_t stream) {
+                double* stats, void* workspace, const int32_t* stop_flag, rs_stream_t stream) {
     if (!actor || !critic || !batch || !grads || !stats || !workspace || batch->M < 1) return RS_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -547,11 +618,11 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
             return RS_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(rs_ppo_grad_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_a, s, to_dev(actor), *batch, pa, sa);
-    hipLaunchKernelGGL(rs_ppo_grad_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_c, s, to_dev(critic), *batch, pc, sc);
+    hipLaunchKernelGGL(rs_ppo_grad_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
+    hipLaunchKernelGGL(rs_ppo_grad_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
     const int np = rs_net_params(8) + rs_net_params(1);
-    hipLaunchKernelGGL(rs_ppo_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, s, pa, pc, sa, sc, waves, grads, stats,
-                       batch->alpha, batch->vf_coef);
+    hipLaunchKernelGGL(rs_ppo_reduce_kernel, dim3((np + 63) / 64), dim3(1024), 0, s, pa, pc, sa, sc, waves, grads, stats,
+                       batch->alpha, batch->vf_coef, stop_flag);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

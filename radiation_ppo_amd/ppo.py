@@ -99,6 +99,10 @@ class FusedPPOGrad:
         # views of the flat gradient in the parameter order of the C ABI
         order = [ac.actor[0].weight, ac.actor[0].bias, ac.actor[2].weight, ac.actor[2].bias, ac.actor[4].weight, ac.actor[4].bias,
                  ac.critic[0].weight, ac.critic[0].bias, ac.critic[2].weight, ac.critic[2].bias, ac.critic[4].weight, ac.critic[4].bias]
+        self.m = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)       # Adam exp_avg
+        self.v = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)       # Adam exp_avg_sq
+        self.state = torch.zeros(8, dtype=torch.float64, device=dev)          # rs_update_state (56 bytes used)
+        self.state_i32 = self.state.view(torch.int32)                         # [adam_step, stopped, iters, pad, ...]
         self.views = []
         o = 0
         for p in order:
@@ -106,7 +110,24 @@ class FusedPPOGrad:
             o += p.numel()
         assert o == N_PARAMS
 
-    def __call__(self, X, act, adv, ret, logp_old, w, clip_ratio: float, alpha: float, vf_coef: float = 0.01):
+    def begin_update(self) -> None:
+        self.state_i32[1:3].zero_()                                           # stopped = 0, iters = 0
+
+    def adam_step(self, lr: float, kl_threshold: float) -> None:
+        import ctypes as C
+        pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
+        _lib.check(self.lib.rs_adam_step(C.byref(pa), C.byref(pc), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         self.stats.data_ptr(), self.state.data_ptr(), lr, kl_threshold,
+                                         torch.cuda.current_stream(self.grads.device).cuda_stream), "rs_adam_step")
+
+    def read_state(self):
+        """(iters, stopped, adam_step, last_stats[5]) -- one host sync."""
+        st = self.state.cpu()
+        i32 = st.view(torch.int32)
+        return int(i32[2]), int(i32[1]), int(i32[0]), st[2:7].tolist()
+
+    def __call__(self, X, act, adv, ret, logp_old, w, clip_ratio: float, alpha: float, vf_coef: float = 0.01,
+                 use_stop_flag: bool = False):
         import ctypes as C
         for t in (X, adv, ret, logp_old, w):
             assert t.dtype == torch.float32 and t.is_contiguous()
@@ -115,7 +136,8 @@ class FusedPPOGrad:
                             X.shape[0], clip_ratio, alpha, vf_coef)
         pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
         _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
-                                        self._ws_ptr, torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
+                                        self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
+                                        torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
         return self.stats, self.grads
 
     def assign_grads(self) -> None:
@@ -226,6 +248,8 @@ class VecAgentPPO:
         self.gamma, self.lam, self.alpha = gamma, lam, alpha
         self.clip_ratio, self.target_kl = clip_ratio, target_kl
         self.train_pi_iters = train_pi_iters
+        self.actor_learning_rate = actor_learning_rate
+        self.epochs_done = 0
         self.agent = FFActorCritic(observation_space, action_space).to(self.device)
         self.pi_optimizer = torch.optim.Adam(self.agent.parameters(), lr=actor_learning_rate)
         self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)   # ppo.py:205-207
@@ -295,24 +319,23 @@ class VecAgentPPO:
                             kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
 
     def _update_agent_fused(self, X, act, adv, ret, logp_old, w) -> UpdateResult:
-        """Same control flow as update_agent, with rs_ppo_grad in place of the autograd forward/backward."""
+        """update_agent / update_rada2c control flow (ppo.py:789-796,1250-1261) with no host round trip inside
+        the loop: rs_ppo_grad computes statistics + gradients, rs_adam_step takes the KL early-stop decision and
+        the Adam step on the device; iterations after the stop are no-ops.  One sync at the end."""
         if self._fused is None:
             self._fused = FusedPPOGrad(self.agent)
-        kk, kl_reached, last, thr = 0, False, None, 1.5 * self.target_kl
-        while not kl_reached and kk < self.train_pi_iters:
-            stats, grads = self._fused(X, act, adv, ret, logp_old, w, self.clip_ratio, self.alpha)
+        f = self._fused
+        lr = self.actor_learning_rate * (0.99 ** (self.epochs_done // 100))   # StepLR(100, 0.99) (ppo.py:205-207)
+        thr = 1.5 * self.target_kl
+        f.begin_update()
+        for _ in range(self.train_pi_iters):
+            stats, grads = f(X, act, adv, ret, logp_old, w, self.clip_ratio, self.alpha, use_stop_flag=True)
             if _world() > 1:
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM)           # mpi_avg(kl) (ppo.py:1250)
-            last = stats.tolist()                                        # the early-stop decision needs the host
-            if last[0] < thr:
-                if _world() > 1:
-                    dist.all_reduce(grads, op=dist.ReduceOp.SUM)       # mpi_avg_grads (ppo.py:1256): one flat bucket
-                self._fused.assign_grads()
-                self.pi_optimizer.step()
-            else:
-                kl_reached = True
-            kk += 1
-        self.pi_scheduler.step()
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM)           # mpi_avg_grads (ppo.py:1256): one flat bucket
+            f.adam_step(lr, thr)
+        kk, stopped, _, last = f.read_state()
+        self.epochs_done += 1
         return UpdateResult(stop_iteration=kk, loss_policy=last[4], loss_critic=last[3], loss_predictor=0.0,
                             kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
 

@@ -308,3 +308,31 @@ def test_fused_ppo_grad_matches_autograd(M):
     # bitwise reproducible (slab reduction, no float atomics)
     stats2, g2 = fused(X, act, adv, ret, lpo, w, 0.2, 0.1)
     assert torch.equal(g2, g.clone()) or torch.equal(g2, g)
+
+
+def test_device_side_update_loop_matches_torch_adam():
+    """The sync-free update (rs_ppo_grad + rs_adam_step per iteration, KL early stop decided on the device)
+    against the same loop written with torch autograd + torch.optim.Adam."""
+    from radiation_ppo_amd.ppo import VecAgentPPO
+    M = 4096
+    torch.manual_seed(7)
+    X = torch.randn(M, 11, device="cuda")
+    act = torch.randint(0, 8, (M,), device="cuda")
+    adv = torch.randn(M, device="cuda")
+    ret = torch.randn(M, device="cuda")
+    w = torch.rand(M, device="cuda"); w = w / w.sum()
+    for target_kl, expect_early in ((10.0, False), (1e-4, True)):
+        torch.manual_seed(11)
+        a1 = VecAgentPPO(id=0, alpha=0.1, train_pi_iters=8, target_kl=target_kl, actor_learning_rate=1e-2)
+        torch.manual_seed(11)
+        a2 = VecAgentPPO(id=0, alpha=0.1, train_pi_iters=8, target_kl=target_kl, actor_learning_rate=1e-2)
+        a2.fused_update = False
+        with torch.no_grad():
+            lpo = a1.agent.evaluate(X, act)[0].clone()
+        r1 = a1.update_agent(X, act, adv, ret, lpo, w)
+        r2 = a2.update_agent(X, act, adv, ret, lpo, w)
+        assert r1.stop_iteration == r2.stop_iteration, (r1, r2)
+        assert (r1.stop_iteration < 8) == expect_early
+        assert abs(r1.kl_divergence - r2.kl_divergence) < 1e-5 and abs(r1.loss_policy - r2.loss_policy) < 1e-4
+        for p1, p2 in zip(a1.agent.parameters(), a2.agent.parameters()):
+            assert torch.allclose(p1, p2, rtol=1e-4, atol=2e-5), (p1 - p2).abs().max()
