@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define RS_HID 64
 #define RS_IN 11
@@ -62,11 +63,11 @@ struct RsMlpLds {
     }
 };
 
-// tanh(x) = sign(x) * (1 - t) / (1 + t), t = exp(-2|x|): v_exp_f32 + v_rcp_f32, abs error < 2e-7
+// tanh(x) = sign(x) * (1 - t) / (1 + t), t = 2^(-2 log2(e) |x|): v_exp_f32 + v_rcp_f32 (raw, 1 ulp), 7 VALU
+// instructions, abs error < 3e-7 (the fp32 tolerance of the policy path is 1e-5)
 __device__ __forceinline__ float rs_tanh(float x) {
-    float ax = fabsf(x);
-    float t = __expf(-2.0f * ax);
-    float r = (1.0f - t) * __frcp_rn(1.0f + t);
+    const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));
+    const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
     return copysignf(r, x);
 }
 
@@ -85,18 +86,21 @@ __device__ __forceinline__ void rs_mlp_layer1(const RsMlpLds<NOUT>& W, const flo
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) H.v[it][jt][r] = W.b1[32 * it + rs_kappa(r, h)];
+    // weight fragments are fetched one k-step ahead of the MFMAs that consume them (LDS latency hidden)
+    float a0 = W.w1f[(0 * 6 + 0) * 64 + lane], a1 = W.w1f[(1 * 6 + 0) * 64 + lane];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const float own = h ? xo[2 * s + 1] : xo[2 * s];
         const float par = h ? xp[2 * s + 1] : xp[2 * s];
         const float b0 = h ? par : own;      // jt = 0: lanes < 32 own the sample
         const float b1 = h ? own : par;      // jt = 1: lanes >= 32 own the sample
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const float a = W.w1f[(it * 6 + s) * 64 + lane];
-            H.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, H.v[it][0], 0, 0, 0);
-            H.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, H.v[it][1], 0, 0, 0);
-        }
+        float n0 = 0.f, n1 = 0.f;
+        if (s + 1 < 6) { n0 = W.w1f[(0 * 6 + s + 1) * 64 + lane]; n1 = W.w1f[(1 * 6 + s + 1) * 64 + lane]; }
+        H.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, H.v[0][0], 0, 0, 0);
+        H.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, H.v[0][1], 0, 0, 0);
+        H.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, H.v[1][0], 0, 0, 0);
+        H.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, H.v[1][1], 0, 0, 0);
+        a0 = n0; a1 = n1;
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -116,22 +120,30 @@ __device__ __forceinline__ void rs_mlp_layer2(const RsMlpLds<NOUT>& W, const RsH
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) H2.v[it][jt][r] = W.b2[32 * it + rs_kappa(r, h)];
+    // out-tile major: the tanh of tile it = 0 (VALU) overlaps the MFMA chain of tile it = 1; weight fragments
+    // are fetched two k-steps ahead of their MFMAs
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int it = 0; it < 2; ++it) {
+        float a_c = W.w2f[((it * 2 + 0) * 16 + 0) * 64 + lane];
+        float a_n = W.w2f[((it * 2 + 0) * 16 + 1) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const float a = W.w2f[((it * 2 + kt) * 16 + r) * 64 + lane];
-                H2.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H1.v[kt][0][r], H2.v[it][0], 0, 0, 0);
-                H2.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H1.v[kt][1][r], H2.v[it][1], 0, 0, 0);
-            }
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
+        for (int q = 0; q < 32; ++q) {
+            const int kt = q >> 4, r = q & 15;
+            float a_nn = 0.f;
+            if (q + 2 < 32) a_nn = W.w2f[((it * 2 + ((q + 2) >> 4)) * 16 + ((q + 2) & 15)) * 64 + lane];
+            H2.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, H1.v[kt][0][r], H2.v[it][0], 0, 0, 0);
+            H2.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, H1.v[kt][1][r], H2.v[it][1], 0, 0, 0);
+            a_c = a_n; a_n = a_nn;
+            // pin the issue order: the fragment read for step q+2, then this step's two MFMAs (hipcc otherwise
+            // sinks the read next to its use and waits lgkmcnt(0) in front of every MFMA pair)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) H2.v[it][jt][r] = rs_tanh(H2.v[it][jt][r]);
+    }
 }
 
 // output layer on the VALU: out[o] for the lane's OWN sample

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(64) rs_rollout_kernel(RsParams P, RsMlpParams 
 #define RS_TS 65                                  // LDS tile row stride (floats)
 
 __host__ __device__ constexpr int rs_net_params(int nout) { return 64 * 11 + 64 + 64 * 64 + 64 + nout * 64 + nout; }
-__host__ __device__ constexpr int rs_grad_lds_floats(int nout) { return rs_mlp_lds_floats(nout) + 2 * 2 * 16 * 64 + 4 * (64 + 32 + 12) * RS_TS; }
+__host__ __device__ constexpr int rs_grad_lds_floats(int nout) { return rs_mlp_lds_floats(nout) + 2 * 2 * 16 * 64 + 2 * 4 * 64 + 4 * (64 + 32 + 12) * RS_TS; }
 
 __device__ __forceinline__ void rs_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
     W.carve(smem_f);
     float* w2tf = smem_f + rs_mlp_lds_floats(NOUT);                    // [2 it][2 kt][16 r][64]: W2[32kt + kappa][32it + (l&31)]
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    float* Qt = w2tf + 2 * 2 * 16 * 64 + wid * (64 + 32 + 12) * RS_TS;   // [64][65]
+    float* w3tf = w2tf + 2 * 2 * 16 * 64;                               // [2 it][4 s][64]: W3[2s + (l>>5)][32it + (l&31)] (actor)
+    float* Qt = w3tf + 2 * 4 * 64 + wid * (64 + 32 + 12) * RS_TS;       // [64][65]
     float* Pt = Qt + 64 * RS_TS;                                        // [32][65]
     float* St = Pt + 32 * RS_TS;                                        // [12][65]
     W.fill(prm);
@@ -269,18 +270,33 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
         int l = i & 63, r = (i >> 6) & 15, kt = (i >> 10) & 1, it = i >> 11;
         w2tf[i] = prm.w2[(32 * kt + rs_kappa(r, l >> 5)) * RS_HID + 32 * it + (l & 31)];
     }
+    for (int i = threadIdx.x; i < 2 * 4 * 64; i += blockDim.x) {
+        int l = i & 63, sq = (i >> 6) & 3, it = i >> 8;
+        int o = 2 * sq + (l >> 5);
+        w3tf[i] = (o < NOUT) ? prm.w3[o * RS_HID + 32 * it + (l & 31)] : 0.0f;
+    }
     __syncthreads();
 
     const int M = B.M;
     const int groups = (M + 63) / 64;
     const int wave_g = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
 
-    f32x16 acc2[2][2], acc1[2], acc3[2], db2[2];
+    // persistent gradient accumulators: dW2 as 2x2 tiles of 32x32 (64 regs); dW1 [64 x 16] and the actor's dW3
+    // [16 x 64] as 4 tiles of 16x16 each (16 + 16 regs, v_mfma_f32_16x16x4_f32); the critic's dW3 [64] as per-lane
+    // partial sums in accumulator layout (32 regs); db2 per-lane partial sums (32 regs)
+    f32x16 acc2[2][2], acc3v[2], db2[2];
+    f32x4 acc1[4], acc3[4];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc2[a][0][r] = 0.f; acc2[a][1][r] = 0.f; acc1[a][r] = 0.f; acc3[a][r] = 0.f; db2[a][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc2[a][0][r] = 0.f; acc2[a][1][r] = 0.f; acc3v[a][r] = 0.f; db2[a][r] = 0.f; }
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc1[a][r] = 0.f; acc3[a][r] = 0.f; }
+    }
+    const int l15 = lane & 15, l4 = lane >> 4;
     float db3[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) db3[o] = 0.f;
@@ -348,96 +364,181 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) { dzp[o] = __shfl_xor(dz[o], 32); db3[o] += dz[o]; }
 
-        // ---- dW3 += dz . h2^T   (A = dz tile from LDS, B = h2^T tile from LDS)
-        rs_stage_half(Qt, H2.v[0], lane);
-        rs_stage_half(Qt + 32 * RS_TS, H2.v[1], lane);
+        // ================= backward =================
+        // Regions R1..R6 are separated by wave-level syncs only where an LDS tile changes hands; inside a
+        // region the MFMA chain and the VALU / LDS-staging work are independent, so they overlap (MFMA executes
+        // asynchronously; one wave per SIMD has no other wave to hide behind).
+        // ---- R1: stage h2^T and dz for dW3 (actor); the critic's dW3 runs on the VALU below
+        if (NOUT == 8) {
+            rs_stage_half(Qt, H2.v[0], lane);
+            rs_stage_half(Qt + 32 * RS_TS, H2.v[1], lane);
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) St[o * RS_TS + lane] = dz[o];
-        rs_wave_sync();
-#pragma unroll 4
-        for (int s = 0; s < 32; ++s) {
-            const float a = (c < NOUT) ? St[c * RS_TS + 2 * s + h] : 0.0f;
-            const float b0 = Qt[c * RS_TS + 2 * s + h], b1 = Qt[(32 + c) * RS_TS + 2 * s + h];
-            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc3[0], 0, 0, 0);
-            acc3[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc3[1], 0, 0, 0);
+            for (int o = 0; o < NOUT; ++o) St[o * RS_TS + lane] = dz[o];
+            rs_wave_sync();
         }
-        // ---- backward through the output layer (VALU): dh2, then dpre2 = dh2 * (1 - h2^2) in place of H2
+        // ---- R2: dW3 += dz . h2^T (matrix cores)  ||  dh2 = W3^T dz, dpre2 = dh2 * (1 - h2^2) (in place of H2)
+        if (NOUT == 8) {
+            // dW3[o][unit] = sum_n dz[o][n] h2[unit][n]: 16x16x4 tiles, A = dz^T tile (rows o < 8), B = h2^T tile
+            {
+                float a_c = (l15 < NOUT) ? St[l15 * RS_TS + l4] : 0.0f;
+                float b_c[4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int u = 0; u < 4; ++u) b_c[u] = Qt[(16 * u + l15) * RS_TS + l4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float d0 = 0.f, d1 = 0.f;
+                for (int s = 0; s < 16; ++s) {
+                    float a_n = 0.f, b_n[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (s + 1 < 16) {
+                        a_n = (l15 < NOUT) ? St[l15 * RS_TS + 4 * (s + 1) + l4] : 0.0f;
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) {
-                    const float wv = W.w3h[(h * NOUT + o) * 32 + kt * 16 + r];
-                    const float z0 = h ? dzp[o] : dz[o];       // sample tile jt = 0 is owned by lanes < 32
-                    const float z1 = h ? dz[o] : dzp[o];
-                    d0 = fmaf(wv, z0, d0);
-                    d1 = fmaf(wv, z1, d1);
+                        for (int u = 0; u < 4; ++u) b_n[u] = Qt[(16 * u + l15) * RS_TS + 4 * (s + 1) + l4];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc3[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[u], acc3[u], 0, 0, 0);
+                    a_c = a_n;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b_c[u] = b_n[u];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
-                const float h20 = H2.v[kt][0][r], h21 = H2.v[kt][1][r];
-                H2.v[kt][0][r] = d0 * (1.0f - h20 * h20);
-                H2.v[kt][1][r] = d1 * (1.0f - h21 * h21);
             }
-        // ---- dW2 += dpre2 . h1^T ; db2 += dpre2
-        rs_wave_sync();
-        rs_stage_half(Qt, H1.v[0], lane);
-        rs_stage_half(Qt + 32 * RS_TS, H1.v[1], lane);
+            // dh2[unit][sample] = sum_o W3[o][unit] dz[o][sample]: K = 8 outputs -> 4 k-steps per 32x32 tile
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            rs_wave_sync();
-            rs_stage_half(Pt, H2.v[it], lane);
-            rs_wave_sync();
-#pragma unroll 4
-            for (int s = 0; s < 32; ++s) {
-                const float a = Pt[c * RS_TS + 2 * s + h];
-                const float b0 = Qt[c * RS_TS + 2 * s + h], b1 = Qt[(32 + c) * RS_TS + 2 * s + h];
-                acc2[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc2[it][0], 0, 0, 0);
-                acc2[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc2[it][1], 0, 0, 0);
+            for (int it = 0; it < 2; ++it) {
+                f32x16 t0, t1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { t0[r] = 0.f; t1[r] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float own = h ? dz[(2 * s + 1) % NOUT] : dz[(2 * s) % NOUT];
+                    const float par = h ? dzp[(2 * s + 1) % NOUT] : dzp[(2 * s) % NOUT];
+                    const float a = w3tf[(it * 4 + s) * 64 + lane];
+                    t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h ? par : own, t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h ? own : par, t1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float h20 = H2.v[it][0][r], h21 = H2.v[it][1][r];
+                    H2.v[it][0][r] = t0[r] * (1.0f - h20 * h20);
+                    H2.v[it][1][r] = t1[r] * (1.0f - h21 * h21);
+                }
             }
+        } else {
+            const float z0 = h ? dzp[0] : dz[0];               // sample tile jt = 0 is owned by lanes < 32
+            const float z1 = h ? dz[0] : dzp[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) db2[it][r] += H2.v[it][0][r] + H2.v[it][1][r];
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float wv = W.w3h[h * 32 + kt * 16 + r];
+                    const float h20 = H2.v[kt][0][r], h21 = H2.v[kt][1][r];
+                    acc3v[kt][r] += z0 * h20 + z1 * h21;       // dW3[unit] partial (this lane's two samples)
+                    H2.v[kt][0][r] = (wv * z0) * (1.0f - h20 * h20);
+                    H2.v[kt][1][r] = (wv * z1) * (1.0f - h21 * h21);
+                }
         }
-        // ---- dh1 = W2^T . dpre2 (accumulator layout in/out), dpre1 = dh1 * (1 - h1^2) in place of H1
+        rs_wave_sync();
+        // ---- R3: dh1 = W2^T . dpre2 (register operands)  ||  stage h1^T -> Qt, dpre2[it=0] -> Pt, x -> St
         RsHidden D1;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { D1.v[it][0][r] = 0.f; D1.v[it][1][r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int it = 0; it < 2; ++it) {
+            float a_c = w2tf[((it * 2 + 0) * 16 + 0) * 64 + lane];
+            float a_n = w2tf[((it * 2 + 0) * 16 + 1) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int q = 0; q < 32; ++q) {
+                const int kt = q >> 4, r = q & 15;
+                float a_nn = 0.f;
+                if (q + 2 < 32) a_nn = w2tf[((it * 2 + ((q + 2) >> 4)) * 16 + ((q + 2) & 15)) * 64 + lane];
+                D1.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, H2.v[kt][0][r], D1.v[it][0], 0, 0, 0);
+                D1.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, H2.v[kt][1][r], D1.v[it][1], 0, 0, 0);
+                a_c = a_n; a_n = a_nn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        rs_stage_half(Qt, H1.v[0], lane);
+        rs_stage_half(Qt + 32 * RS_TS, H1.v[1], lane);
+        rs_stage_half(Pt, H2.v[0], lane);
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const float a = w2tf[((it * 2 + kt) * 16 + r) * 64 + lane];
-                    D1.v[it][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H2.v[kt][0][r], D1.v[it][0], 0, 0, 0);
-                    D1.v[it][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, H2.v[kt][1][r], D1.v[it][1], 0, 0, 0);
+        for (int k = 0; k < RS_IN; ++k) St[k * RS_TS + lane] = xo[k];
+        St[11 * RS_TS + lane] = 1.0f;                           // x[11] := 1 -> column 11 of dW1 is db1
+        rs_wave_sync();
+        // ---- R4: dW2[it=0] += dpre2[0] . h1^T  ||  dpre1 = dh1 * (1 - h1^2) (in place of D1), db2
+        {
+            float a_c = Pt[c * RS_TS + h], b0_c = Qt[c * RS_TS + h], b1_c = Qt[(32 + c) * RS_TS + h];
+            float a_n = Pt[c * RS_TS + 2 + h], b0_n = Qt[c * RS_TS + 2 + h], b1_n = Qt[(32 + c) * RS_TS + 2 + h];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                float a_nn = 0.f, b0_nn = 0.f, b1_nn = 0.f;
+                if (s + 2 < 32) {
+                    a_nn = Pt[c * RS_TS + 2 * (s + 2) + h];
+                    b0_nn = Qt[c * RS_TS + 2 * (s + 2) + h];
+                    b1_nn = Qt[(32 + c) * RS_TS + 2 * (s + 2) + h];
                 }
+                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b0_c, acc2[0][0], 0, 0, 0);
+                acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b1_c, acc2[0][1], 0, 0, 0);
+                a_c = a_n; b0_c = b0_n; b1_c = b1_n;
+                a_n = a_nn; b0_n = b0_nn; b1_n = b1_nn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float hv = H1.v[it][jt][r];
-                    D1.v[it][jt][r] = D1.v[it][jt][r] * (1.0f - hv * hv);
-                }
-        // ---- dW1 += dpre1 . x^T with x[11] := 1, so column 11 of the product is db1
+            for (int r = 0; r < 16; ++r) {
+                db2[it][r] += H2.v[it][0][r] + H2.v[it][1][r];
+                const float h0 = H1.v[it][0][r], h1v = H1.v[it][1][r];
+                D1.v[it][0][r] = D1.v[it][0][r] * (1.0f - h0 * h0);
+                D1.v[it][1][r] = D1.v[it][1][r] * (1.0f - h1v * h1v);
+            }
         rs_wave_sync();
+        // ---- R5: dW2[it=1]
+        rs_stage_half(Pt, H2.v[1], lane);
+        rs_wave_sync();
+        {
+            float a_c = Pt[c * RS_TS + h], b0_c = Qt[c * RS_TS + h], b1_c = Qt[(32 + c) * RS_TS + h];
+            float a_n = Pt[c * RS_TS + 2 + h], b0_n = Qt[c * RS_TS + 2 + h], b1_n = Qt[(32 + c) * RS_TS + 2 + h];
 #pragma unroll
-        for (int k = 0; k < RS_IN; ++k) St[k * RS_TS + lane] = xo[k];
-        St[11 * RS_TS + lane] = 1.0f;
+            for (int s = 0; s < 32; ++s) {
+                float a_nn = 0.f, b0_nn = 0.f, b1_nn = 0.f;
+                if (s + 2 < 32) {
+                    a_nn = Pt[c * RS_TS + 2 * (s + 2) + h];
+                    b0_nn = Qt[c * RS_TS + 2 * (s + 2) + h];
+                    b1_nn = Qt[(32 + c) * RS_TS + 2 * (s + 2) + h];
+                }
+                acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b0_c, acc2[1][0], 0, 0, 0);
+                acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b1_c, acc2[1][1], 0, 0, 0);
+                a_c = a_n; b0_c = b0_n; b1_c = b1_n;
+                a_n = a_nn; b0_n = b0_nn; b1_n = b1_nn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        }
+        // ---- R6: dW1[unit][input] += sum_n dpre1[unit][n] x[input][n]: 16x16x4 tiles (4 unit tiles x 1 input tile)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             rs_wave_sync();
             rs_stage_half(Pt, D1.v[it], lane);
             rs_wave_sync();
-#pragma unroll 4
-            for (int s = 0; s < 32; ++s) {
-                const float a = Pt[c * RS_TS + 2 * s + h];
-                const float b = (c < RS_IN_PAD) ? St[c * RS_TS + 2 * s + h] : 0.0f;
-                acc1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1[it], 0, 0, 0);
+            float b_c = (l15 < RS_IN_PAD) ? St[l15 * RS_TS + l4] : 0.0f;
+            float a0_c = Pt[l15 * RS_TS + l4], a1_c = Pt[(16 + l15) * RS_TS + l4];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float b_n = 0.f, a0_n = 0.f, a1_n = 0.f;
+                if (s + 1 < 16) {
+                    b_n = (l15 < RS_IN_PAD) ? St[l15 * RS_TS + 4 * (s + 1) + l4] : 0.0f;
+                    a0_n = Pt[l15 * RS_TS + 4 * (s + 1) + l4];
+                    a1_n = Pt[(16 + l15) * RS_TS + 4 * (s + 1) + l4];
+                }
+                acc1[2 * it + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_c, b_c, acc1[2 * it + 0], 0, 0, 0);
+                acc1[2 * it + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_c, b_c, acc1[2 * it + 1], 0, 0, 0);
+                b_c = b_n; a0_c = a0_n; a1_c = a1_n;
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
         }
         rs_wave_sync();
@@ -453,17 +554,38 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
             const int row = 32 * it + rs_kappa(r, h);
             g_w2[row * 64 + c] = acc2[it][0][r];
             g_w2[row * 64 + 32 + c] = acc2[it][1][r];
-            if (c < RS_IN) g_w1[row * RS_IN + c] = acc1[it][r];
-            if (c == RS_IN) g_b1[row] = acc1[it][r];
             // db2: sum the 32 lanes that share this (r, h)
             float v = db2[it][r];
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
             if (c == 0) g_b2[row] = v;
         }
+    // dW1 tiles (16x16x4 layout): unit = 16u + 4*(lane>>4) + q, input = lane&15; input 11 carries db1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = rs_kappa(r, h);
-        if (o < NOUT) { g_w3[o * 64 + c] = acc3[0][r]; g_w3[o * 64 + 32 + c] = acc3[1][r]; }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * u + 4 * l4 + q;
+            if (l15 < RS_IN) g_w1[row * RS_IN + l15] = acc1[u][q];
+            if (l15 == RS_IN) g_b1[row] = acc1[u][q];
+        }
+    if (NOUT == 8) {
+        // dW3 tiles: output o = 4*(lane>>4) + q (< 8), unit = 16u + (lane&15)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = 4 * l4 + q;
+                if (o < NOUT) g_w3[o * 64 + 16 * u + l15] = acc3[u][q];
+            }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc3v[kt][r];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+                if (c == 0) g_w3[32 * kt + rs_kappa(r, h)] = v;
+            }
     }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
