@@ -12,8 +12,10 @@ the loop (forward, sampling, env step, buffer write, resets), the GAE pass, and 
 (<= 40 Adam steps with KL early stop).  Nothing is skipped inside the timed region.
     value        = env steps/s over the whole job  = K * 480 * (4096 * N) / wall
     ms_per_step  = wall per PPO iteration (PPO iters/s = 1000 / ms_per_step)
-Rank 0 prints ONE JSON line; it also carries `roofline` (env-step kernel, measured with HIP events in
-this run) and `cpu_baseline` (the oracle -- a port of the reference's Python env -- on the host cores).
+Rank 0 prints ONE JSON line; it also carries `roofline` (the dominant kernel of the iteration: the fused PPO
+loss+gradient pass, MFMA bound), `roofline_env_step` / `roofline_env_step_large_n` (the env-step kernel, HBM
+class, at 4096 and 2^20 envs) -- all timed with HIP events in this run -- and `cpu_baseline` (the oracle, a
+port of the reference's Python env, on the host cores).
 """
 import argparse
 import json
@@ -100,6 +102,34 @@ def time_step_kernel(env, reps: int = 400):
     t1.record()
     torch.cuda.synchronize()
     return {"avg_ms": sum(ds) / len(ds), "median_ms": ds[len(ds) // 2], "train_ms": t0.elapsed_time(t1) / reps}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (MI355X_MICROARCH.md, Matrix cores table)
+# algorithmic FLOPs per sample of one PPO loss+gradient pass over the FF_core actor+critic:
+#   forward  2*(11*64 + 64*64 + 64*8) + 2*(11*64 + 64*64 + 64*1)                     = 20 352  (20.4 kFLOP)
+#   backward 2*(512+512+4096+4096+704) [actor dW3,dh2,dW2,dh1,dW1] + 2*(64+64+4096+4096+704) = 37 888
+PPO_GRAD_FLOPS_PER_SAMPLE = 58240
+
+
+def time_grad_pass(col, reps: int = 20):
+    """Average duration of one fused PPO loss+gradient pass (rs_ppo_grad: actor kernel + critic kernel + slab
+    reduce) over the epoch's batch, HIP events on the launch stream."""
+    from radiation_ppo_amd.ppo import FusedPPOGrad
+    buf = col.buf
+    ag = col.agents[0]
+    X = buf.obs[:, :, 0].reshape(-1, 11)
+    act, adv, ret, lpo = (t.reshape(-1) for t in (buf.act, buf.adv, buf.ret, buf.logp))
+    w = torch.full_like(adv, 1.0 / adv.numel())
+    f = ag._fused if getattr(ag, "_fused", None) is not None else FusedPPOGrad(ag.agent)
+    f(X, act, adv, ret, lpo, w, 0.2, 0.1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f(X, act, adv, ret, lpo, w, 0.2, 0.1)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, X.shape[0]
 
 
 def main():
@@ -190,27 +220,35 @@ def main():
     }
 
     if rank == 0:
+        # dominant kernel of the PPO iteration: the fused loss+gradient pass (<= 40 launches per iteration), MFMA bound
+        if args.collector == "fused":
+            g_ms, g_m = time_grad_pass(col)
+            tfl = PPO_GRAD_FLOPS_PER_SAMPLE * g_m / (g_ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad_kernel<8> + rs_ppo_grad_kernel<1> (+ rs_ppo_reduce_kernel)",
+                                  "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
+                                  "traffic": None, "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
+                                  "avg_launch_ms": g_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
         k1 = time_step_kernel(env)
         bytes_per_launch = K1_BYTES_PER_AGENT_STEP * N * 1
         achieved = bytes_per_launch / (k1["avg_ms"] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        result["roofline_env_step"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                               "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1["avg_ms"],
                               "median_launch_ms": k1["median_ms"], "back_to_back_ms": k1["train_ms"],
                               "env_only_steps_per_s": N / (k1["train_ms"] * 1e-3),
-                              "note": "4096 envs = 0.64 MB per launch: launch-latency bound, see roofline_large_n"}
+                              "note": "4096 envs = 0.64 MB per launch: launch-latency bound, see roofline_env_step_large_n"}
         # the same kernel where it is bandwidth-sized: 2^20 envs
         try:
             big = RadSearchVec(1 << 20, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED, device=dev)
             kb = time_step_kernel(big, reps=60)
             bpl = K1_BYTES_PER_AGENT_STEP * (1 << 20)
             ach = bpl / (kb["avg_ms"] * 1e-3) / 1e9
-            result["roofline_large_n"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "envs": 1 << 20, "achieved": ach,
+            result["roofline_env_step_large_n"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "envs": 1 << 20, "achieved": ach,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                           "avg_launch_ms": kb["avg_ms"], "env_only_steps_per_s": (1 << 20) / (kb["train_ms"] * 1e-3)}
             del big
         except Exception as e:  # noqa: BLE001
-            result["roofline_large_n"] = {"error": repr(e)}
+            result["roofline_env_step_large_n"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(result), flush=True)

@@ -108,10 +108,8 @@ def poisson_from_uniforms(lam, next_uv):
             else:
                 return x
     slam = math.sqrt(lam)
-    loglam = math.log(lam)
     b = 0.931 + 2.53 * slam
     a = -0.059 + 0.02483 * b
-    invalpha = 1.1239 + 1.1328 / (b - 3.4)
     vr = 0.9277 - 3.6224 / (b - 2.0)
     i = 0
     while True:
@@ -124,8 +122,20 @@ def poisson_from_uniforms(lam, next_uv):
             return int(k)
         if k < 0 or (us < 0.013 and v > us):
             continue
-        logv = math.log(v) if v > 0.0 else -math.inf
-        if (logv + math.log(invalpha) - math.log(a / (us * us) + b)) <= (-lam + k * loglam - math.lgamma(k + 1.0)):
+        # slow path: one log on the left; Stirling series of lgamma(x), x = k+1 >= 10, on the right (the same
+        # formula, operation for operation, as rs_poisson in radiation_ppo_amd/csrc/rs_device.hpp)
+        invalpha = 1.1239 + 1.1328 / (b - 3.4)
+        arg = v * invalpha / (a / (us * us) + b)
+        lhs = math.log(arg) if arg > 0.0 else -math.inf
+        x = k + 1.0
+        if x >= 10.0:
+            xi = 1.0 / x
+            xi2 = xi * xi
+            ser = xi * (0.083333333333333333 - xi2 * (0.0027777777777777778 - xi2 * (0.00079365079365079365 - xi2 * 0.00059523809523809524)))
+            rhs = k * math.log(lam / x) - 0.5 * math.log(x) - lam + x - 0.91893853320467274 - ser
+        else:
+            rhs = -lam + k * math.log(lam) - math.lgamma(x)
+        if lhs <= rhs:
             return int(k)
 
 

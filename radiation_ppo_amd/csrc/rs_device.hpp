@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rs_tables.hpp"
+
 #define RS_WAVE 64
 #define RS_OBS_DIM 11
 #define RS_MAX_AGENTS 8
@@ -111,10 +113,8 @@ __device__ __forceinline__ int64_t rs_poisson(double lam, uint32_t t, uint32_t e
         }
     }
     double slam = sqrt(lam);
-    double loglam = log(lam);
     double b = 0.931 + 2.53 * slam;
     double a = -0.059 + 0.02483 * b;
-    double invalpha = 1.1239 + 1.1328 / (b - 3.4);
     double vr = 0.9277 - 3.6224 / (b - 2.0);
     for (uint32_t i = 0;; ++i) {
         u32x4 o = philox4x32_10(i, t, episode, stream, k0, k1);
@@ -125,8 +125,21 @@ __device__ __forceinline__ int64_t rs_poisson(double lam, uint32_t t, uint32_t e
         double k = floor((2.0 * a / us + b) * u + lam + 0.43);
         if (us >= 0.07 && v <= vr) return (int64_t)k;
         if (k < 0.0 || (us < 0.013 && v > us)) continue;
-        double lhs = log(v) + log(invalpha) - log(a / (us * us) + b);
-        double rhs = -lam + k * loglam - lgamma(k + 1.0);
+        // slow path (~10 % of the draws).  Hormann's test  log(V) + log(invalpha) - log(a/us^2 + b)  <=
+        // -lam + k log(lam) - lgamma(k+1)  evaluated with ONE log on the left and, for x = k+1 >= 10, the
+        // Stirling series of lgamma on the right (truncation error < 1e-12 at x = 10):
+        //   rhs = k log(lam/x) - log(x)/2 - lam + x - log(2 pi)/2 - (1/(12x) - 1/(360x^3) + 1/(1260x^5) - 1/(1680x^7))
+        const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+        const double lhs = log(v * invalpha / (a / (us * us) + b));
+        const double x = k + 1.0;
+        double rhs;
+        if (x >= 10.0) {
+            const double xi = 1.0 / x, xi2 = xi * xi;
+            const double ser = xi * (0.083333333333333333 - xi2 * (0.0027777777777777778 - xi2 * (0.00079365079365079365 - xi2 * 0.00059523809523809524)));
+            rhs = k * log(lam / x) - 0.5 * log(x) - lam + x - 0.91893853320467274 - ser;
+        } else {
+            rhs = -lam + k * log(lam) - lgamma(x);
+        }
         if (lhs <= rhs) return (int64_t)k;
     }
 }
@@ -149,6 +162,7 @@ __device__ __forceinline__ double rs_round2(double x) {
     uint64_t rem = P & ((1ull << s) - 1ull);
     uint64_t half = 1ull << (s - 1);
     if (rem > half || (rem == half && (q & 1ull))) q += 1;
+    if (q < 256ull) return sgn * RS_CENT_TAB[q];           // == (double)q / 100.0, looked up
     return sgn * ((double)q / 100.0);
 }
 
@@ -199,6 +213,8 @@ __device__ __forceinline__ bool rs_frac_lt(int n1, int d1, int n2, int d2) { ret
 
 // closed segment p-q meets the OPEN interior of [x0,x1]x[y0,y1]?  (exact)
 __device__ __forceinline__ bool rs_seg_hits_open_rect(int px, int py, int qx, int qy, int x0, int y0, int x1, int y1) {
+    // exact prune: the segment's bounding box does not reach into the open rectangle
+    if (max(px, qx) <= x0 || min(px, qx) >= x1 || max(py, qy) <= y0 || min(py, qy) >= y1) return false;
     int dx = qx - px, dy = qy - py;
     int ln = -1, ld = 1, un = 2, ud = 1;      // t in (-1, 2) to start: neutral bounds
     bool has = false;
@@ -246,6 +262,8 @@ __device__ __forceinline__ void rs_edge(int e, int x0, int y0, int x1, int y1, i
 
 // vis.boundary_distance(Line_Segment(p,q), rect) < 0.001, exact
 __device__ __forceinline__ bool rs_seg_rect_close(int px, int py, int qx, int qy, int x0, int y0, int x1, int y1) {
+    // exact prune: bounding boxes at least 1 apart => distance >= 1 > 0.001
+    if (max(px, qx) < x0 - 1 || min(px, qx) > x1 + 1 || max(py, qy) < y0 - 1 || min(py, qy) > y1 + 1) return false;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         int ax, ay, bx, by; rs_edge(e, x0, y0, x1, y1, ax, ay, bx, by);
@@ -330,7 +348,14 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
     double d8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) d8[i] = 0.0;
-    if (HAS_OBS && g.n > 0) {
+    uint32_t near = 0;         // obstacles whose rectangle a 100 cm probe can reach at all (exact prune)
+    if (HAS_OBS) {
+        for (int o = 0; o < g.n; ++o) {
+            int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+            if (!(px + 100 < x0 || px - 100 > x1 || py + 100 < y0 || py - 100 > y1)) near |= 1u << o;
+        }
+    }
+    if (HAS_OBS && near != 0) {
         uint64_t cnt = 0;      // obs_idx_ls packed 8 bits per obstacle
         int ones = 0;
 #pragma unroll
@@ -340,6 +365,7 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
             int inter = 0;
             double dmax = 0.0;
             for (int o = 0; o < g.n; ++o) {
+                if (!(near >> o & 1u)) continue;
                 int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
                 double m = 0.0;
 #pragma unroll
@@ -401,14 +427,16 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
             }
         }
     }
-    if (P.enforce) {
-        if ((double)px - 110.0 < (double)P.bx0) d8[0] = (110.0 - fabs((double)(px - P.bx0))) / 110.0;
-        if ((double)py - 110.0 < (double)P.by0) d8[6] = (110.0 - fabs((double)(py - P.by0))) / 110.0;
-        if ((double)P.bx1 <= (double)px + 110.0) d8[4] = (110.0 - fabs((double)(P.bx1 - px))) / 110.0;
-        if ((double)P.by1 <= (double)py + 110.0) d8[2] = (110.0 - fabs((double)(P.by1 - py))) / 110.0;
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = (float)d8[i];
+    if (P.enforce) {
+        // walls (:1232-1259): (DIST_TH - |x - wall|) / DIST_TH with an integer distance 0..110 -> exact table
+        const int dl = abs(px - P.bx0), dd = abs(py - P.by0), dr = abs(P.bx1 - px), du = abs(P.by1 - py);
+        if (px - 110 < P.bx0) out[0] = (dl <= 110) ? RS_WALL_TAB[dl] : (float)((110.0 - (double)dl) / 110.0);
+        if (py - 110 < P.by0) out[6] = (dd <= 110) ? RS_WALL_TAB[dd] : (float)((110.0 - (double)dd) / 110.0);
+        if (P.bx1 <= px + 110) out[4] = (dr <= 110) ? RS_WALL_TAB[dr] : (float)((110.0 - (double)dr) / 110.0);
+        if (P.by1 <= py + 110) out[2] = (du <= 110) ? RS_WALL_TAB[du] : (float)((110.0 - (double)du) / 110.0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@
 // ------------------------------------------------------------------------------------------------
 // K1: RadSearch.step for N envs (rad_search_env.py:443-728)
 template <bool HAS_OBS>
-__global__ void __launch_bounds__(64) rs_step_kernel(RsParams P, const int8_t* __restrict__ actions, float* obs, RsOut O) {
+__global__ void __launch_bounds__(64, (HAS_OBS ? 4 : 1)) rs_step_kernel(RsParams P, const int8_t* __restrict__ actions, float* obs, RsOut O) {
     extern __shared__ __align__(16) unsigned char smem[];
     int* lds_geo = reinterpret_cast<int*>(smem);
     float* tile = reinterpret_cast<float*>(smem + (HAS_OBS ? RS_MAX_VERT * RS_WAVE * 4 : 0));
