@@ -282,14 +282,13 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
     const int wave_g = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
 
     // persistent gradient accumulators: dW2 as 2x2 tiles of 32x32 (64 regs); dW1 [64 x 16] and the actor's dW3
-    // [16 x 64] as 4 tiles of 16x16 each (16 + 16 regs, v_mfma_f32_16x16x4_f32); the critic's dW3 [64] as per-lane
-    // partial sums in accumulator layout (32 regs); db2 per-lane partial sums (32 regs)
-    f32x16 acc2[2][2], acc3v[2], db2[2];
+    // [NOUT(<=16) x 64] as 4 tiles of 16x16 each (16 + 16 regs, v_mfma_f32_16x16x4_f32); db2 per-lane partial sums (32 regs)
+    f32x16 acc2[2][2], db2[2];
     f32x4 acc1[4], acc3[4];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc2[a][0][r] = 0.f; acc2[a][1][r] = 0.f; acc3v[a][r] = 0.f; db2[a][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc2[a][0][r] = 0.f; acc2[a][1][r] = 0.f; db2[a][r] = 0.f; }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -368,8 +367,8 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
         // Regions R1..R6 are separated by wave-level syncs only where an LDS tile changes hands; inside a
         // region the MFMA chain and the VALU / LDS-staging work are independent, so they overlap (MFMA executes
         // asynchronously; one wave per SIMD has no other wave to hide behind).
-        // ---- R1: stage h2^T and dz for dW3 (actor); the critic's dW3 runs on the VALU below
-        if (NOUT == 8) {
+        // ---- R1: stage h2^T and dz^T for dW3
+        {
             rs_stage_half(Qt, H2.v[0], lane);
             rs_stage_half(Qt + 32 * RS_TS, H2.v[1], lane);
 #pragma unroll
@@ -377,8 +376,8 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
             rs_wave_sync();
         }
         // ---- R2: dW3 += dz . h2^T (matrix cores)  ||  dh2 = W3^T dz, dpre2 = dh2 * (1 - h2^2) (in place of H2)
-        if (NOUT == 8) {
-            // dW3[o][unit] = sum_n dz[o][n] h2[unit][n]: 16x16x4 tiles, A = dz^T tile (rows o < 8), B = h2^T tile
+        {
+            // dW3[o][unit] = sum_n dz[o][n] h2[unit][n]: 16x16x4 tiles, A = dz^T tile (rows o < NOUT), B = h2^T tile
             {
                 float a_c = (l15 < NOUT) ? St[l15 * RS_TS + l4] : 0.0f;
                 float b_c[4];
@@ -401,6 +400,8 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
             }
+        }
+        if (NOUT == 8) {
             // dh2[unit][sample] = sum_o W3[o][unit] dz[o][sample]: K = 8 outputs -> 4 k-steps per 32x32 tile
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -431,7 +432,6 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
                 for (int r = 0; r < 16; ++r) {
                     const float wv = W.w3h[h * 32 + kt * 16 + r];
                     const float h20 = H2.v[kt][0][r], h21 = H2.v[kt][1][r];
-                    acc3v[kt][r] += z0 * h20 + z1 * h21;       // dW3[unit] partial (this lane's two samples)
                     H2.v[kt][0][r] = (wv * z0) * (1.0f - h20 * h20);
                     H2.v[kt][1][r] = (wv * z1) * (1.0f - h21 * h21);
                 }
@@ -568,25 +568,14 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
             if (l15 < RS_IN) g_w1[row * RS_IN + l15] = acc1[u][q];
             if (l15 == RS_IN) g_b1[row] = acc1[u][q];
         }
-    if (NOUT == 8) {
-        // dW3 tiles: output o = 4*(lane>>4) + q (< 8), unit = 16u + (lane&15)
+    // dW3 tiles: output o = 4*(lane>>4) + q (< NOUT), unit = 16u + (lane&15)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = 4 * l4 + q;
-                if (o < NOUT) g_w3[o * 64 + 16 * u + l15] = acc3[u][q];
-            }
-    } else {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc3v[kt][r];
-                v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-                if (c == 0) g_w3[32 * kt + rs_kappa(r, h)] = v;
-            }
-    }
+        for (int q = 0; q < 4; ++q) {
+            const int o = 4 * l4 + q;
+            if (o < NOUT) g_w3[o * 64 + 16 * u + l15] = acc3[u][q];
+        }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         float v = db3[o];
