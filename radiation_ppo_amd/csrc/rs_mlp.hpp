@@ -21,6 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RS_HID 64
 #define RS_IN 11
 #define RS_IN_PAD 12
+#define RS_TANH_PRESCALE 2.885390081777927f   // 2 log2(e): see rs_tanh_scaled
 
 // torch layout, row-major [out][in]
 struct RsMlpParams { const float *w1, *b1, *w2, *b2, *w3, *b3; };
@@ -32,6 +33,7 @@ __device__ __forceinline__ int rs_kappa(int r, int h) { return (r & 3) + 8 * (r 
 
 template <int NOUT>
 struct RsMlpLds {
+    // w1f, b1, w2f, b2 are stored multiplied by 2 log2(e) (see rs_tanh_scaled)
     float* w1f;   // [2 it][6 s][64 lanes]      W1[32it + (l&31)][2s + (l>>5)]   (k = 11 -> 0)
     float* b1;    // [64]
     float* w2f;   // [2 it][2 kt][16 r][64]     W2[32it + (l&31)][32kt + kappa(r, l>>5)]
@@ -48,27 +50,28 @@ struct RsMlpLds {
         for (int i = tid; i < 2 * 6 * 64; i += nt) {
             int l = i & 63, s = (i >> 6) % 6, it = i / (6 * 64);
             int row = 32 * it + (l & 31), k = 2 * s + (l >> 5);
-            w1f[i] = (k < RS_IN) ? p.w1[row * RS_IN + k] : 0.0f;
+            w1f[i] = (k < RS_IN) ? RS_TANH_PRESCALE * p.w1[row * RS_IN + k] : 0.0f;
         }
         for (int i = tid; i < 2 * 2 * 16 * 64; i += nt) {
             int l = i & 63, r = (i >> 6) & 15, kt = (i >> 10) & 1, it = i >> 11;
-            w2f[i] = p.w2[(32 * it + (l & 31)) * RS_HID + 32 * kt + rs_kappa(r, l >> 5)];
+            w2f[i] = RS_TANH_PRESCALE * p.w2[(32 * it + (l & 31)) * RS_HID + 32 * kt + rs_kappa(r, l >> 5)];
         }
         for (int i = tid; i < 2 * NOUT * 32; i += nt) {
             int q = i & 31, o = (i >> 5) % NOUT, h = i / (32 * NOUT);
             w3h[i] = p.w3[o * RS_HID + 32 * (q >> 4) + rs_kappa(q & 15, h)];
         }
-        for (int i = tid; i < 64; i += nt) { b1[i] = p.b1[i]; b2[i] = p.b2[i]; }
+        for (int i = tid; i < 64; i += nt) { b1[i] = RS_TANH_PRESCALE * p.b1[i]; b2[i] = RS_TANH_PRESCALE * p.b2[i]; }
         for (int i = tid; i < NOUT; i += nt) b3[i] = p.b3[i];
     }
 };
 
-// tanh(x) = sign(x) * (1 - t) / (1 + t), t = 2^(-2 log2(e) |x|): v_exp_f32 + v_rcp_f32 (raw, 1 ulp), 7 VALU
-// instructions, abs error < 3e-7 (the fp32 tolerance of the policy path is 1e-5)
-__device__ __forceinline__ float rs_tanh(float x) {
-    const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));
-    const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-    return copysignf(r, x);
+// tanh from a PRE-SCALED pre-activation y = 2 log2(e) x  (the LDS copies of W1, b1, W2, b2 carry the factor):
+//   tanh(x) = 1 - 2 / (1 + 2^y)   ->  v_exp_f32, v_add_f32, v_rcp_f32, v_fma_f32: 4 VALU instructions.
+// The f32-input MFMA runs on the same FP32 lanes as the VALU (both 64 FLOP/clk/SIMD), so VALU instructions
+// do not hide behind MFMAs -- every instruction saved here is wall time.  abs error < 3e-7.
+__device__ __forceinline__ float rs_tanh_scaled(float y) {
+    const float e = __builtin_amdgcn_exp2f(y);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
 // Hidden activations of one net for the wave's 64 samples, kept in accumulator layout:
@@ -107,7 +110,7 @@ __device__ __forceinline__ void rs_mlp_layer1(const RsMlpLds<NOUT>& W, const flo
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) H.v[it][jt][r] = rs_tanh(H.v[it][jt][r]);
+            for (int r = 0; r < 16; ++r) H.v[it][jt][r] = rs_tanh_scaled(H.v[it][jt][r]);
 }
 
 // layer 2: accumulator layout in -> accumulator layout out (pre-activation in Z when KEEP_PRE, tanh in H2)
@@ -142,7 +145,7 @@ __device__ __forceinline__ void rs_mlp_layer2(const RsMlpLds<NOUT>& W, const RsH
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) H2.v[it][jt][r] = rs_tanh(H2.v[it][jt][r]);
+            for (int r = 0; r < 16; ++r) H2.v[it][jt][r] = rs_tanh_scaled(H2.v[it][jt][r]);
     }
 }
 

@@ -2,6 +2,7 @@
 // (rs_rollout) and the fused PPO loss/gradient pass (rs_ppo_grad).  See rs_mlp.hpp for the MFMA mapping.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/radsearch.h"
@@ -591,6 +592,8 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
     }
 }
 
+#include "rs_ppo_grad2.hpp"
+
 // deterministic reduction of the per-wave slabs: a workgroup owns 64 consecutive parameters; 16 thread
 // groups each sum a fixed 1/16 of the slabs in order (coalesced 256-byte rows), then the 16 partial sums are
 // added in a fixed order through LDS.  Same order every launch -> bitwise reproducible gradients.
@@ -690,8 +693,14 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
+static int rs_grad_version() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RS_GRAD_V"); v = (e && e[0] == '1') ? 1 : 2; }
+    return v;
+}
+
 size_t rs_ppo_grad_workspace_bytes(void) {
-    const size_t waves = RS_GRAD_BLOCKS * 4;
+    const size_t waves = RS_GRAD_BLOCKS * 8;
     return waves * (size_t)(rs_net_params(8) + rs_net_params(1)) * sizeof(float) + 2 * waves * 5 * sizeof(double) + 512;
 }
 
@@ -716,21 +725,30 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     if (!actor || !critic || !batch || !grads || !stats || !workspace || batch->M < 1) return RS_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int waves = RS_GRAD_BLOCKS * 4;
+    const bool v2 = rs_grad_version() == 2;
+    const int waves = RS_GRAD_BLOCKS * (v2 ? 8 : 4);
     float* pa = static_cast<float*>(workspace);
     float* pc = pa + (size_t)waves * rs_net_params(8);
     double* sa = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pc + (size_t)waves * rs_net_params(1)) + 255) & ~uintptr_t(255));
     double* sc = sa + (size_t)waves * 5;
     static bool attr_set = false;
-    const size_t lds_a = sizeof(float) * (size_t)rs_grad_lds_floats(8), lds_c = sizeof(float) * (size_t)rs_grad_lds_floats(1);
+    const size_t lds_a = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(8) : rs_grad_lds_floats(8));
+    const size_t lds_c = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(1) : rs_grad_lds_floats(1));
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
+        const void* ka = v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<8>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>);
+        const void* kc = v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<1>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>);
+        if (hipFuncSetAttribute(ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
+            hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
             return RS_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(rs_ppo_grad_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
-    hipLaunchKernelGGL(rs_ppo_grad_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    if (v2) {
+        hipLaunchKernelGGL(rs_ppo_grad2_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
+        hipLaunchKernelGGL(rs_ppo_grad2_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    } else {
+        hipLaunchKernelGGL(rs_ppo_grad_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
+        hipLaunchKernelGGL(rs_ppo_grad_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(256), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    }
     const int np = rs_net_params(8) + rs_net_params(1);
     hipLaunchKernelGGL(rs_ppo_reduce_kernel, dim3((np + 63) / 64), dim3(1024), 0, s, pa, pc, sa, sc, waves, grads, stats,
                        batch->alpha, batch->vf_coef, stop_flag);
