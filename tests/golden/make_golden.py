@@ -345,6 +345,77 @@ def gen_welford():
     print("wrote welford.npz")
 
 
+def gen_maps():
+    """MapsBuffer.observation_to_map (algos/multiagent/NeuralNetworkCores/RADTEAM_core.py:532-616) driven by
+    observation dicts from an obstacle env (inputs come from the repo's own env oracle; the EXPECTED maps come
+    from the reference class).  Also records calculate_resolution_accuracy / map dimensions / the log-scale
+    normaliser so the restatement's constants are pinned."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.radsearch_oracle import PhiloxDraws, RadSearchOracle
+    from algos.multiagent.NeuralNetworkCores import RADTEAM_core as R
+    A, L = 3, 20
+    scale = 1 / 2200.0
+    ra = R.calculate_resolution_accuracy(resolution_multiplier=0.01, scale=scale)
+    offset = scale * max((200.0, 500.0))
+    bufs = {i: R.MapsBuffer(observation_dimension=11, steps_per_episode=L, number_of_agents=A, grid_bounds=(1, 1),
+                            resolution_accuracy=ra, offset=offset, resolution_multiplier=0.01) for i in range(A)}
+    env = RadSearchOracle(PhiloxDraws(77, 5), number_agents=A, obstruction_count=4, enforce_grid_boundaries=True)
+    rng = np.random.default_rng(4)
+    obs_log, pred_log, maps_log, reset_log = [], [], [], []
+    obs = env._ret[0]
+    steps = 0
+    for t in range(70):
+        od = {i: np.array(obs[i], dtype=np.float64) for i in range(A)}
+        pred = (float(rng.uniform(0, 1.2)), float(rng.uniform(0, 1.2)))
+        stacks = []
+        for i in range(A):
+            m = bufs[i].observation_to_map(od, i, pred)
+            stacks.append(np.stack([np.array(x, dtype=np.float32) for x in m]))
+        obs_log.append(np.stack([od[i] for i in range(A)]))
+        pred_log.append(pred)
+        maps_log.append(np.stack(stacks))
+        acts = {i: int(rng.integers(0, 9)) for i in range(A)}
+        if t % 9 == 4:
+            acts = {i: 8 for i in range(A)}           # idle: revisits (median / visit-count paths)
+        obs = env.step(acts)[0]
+        steps += 1
+        do_reset = env.done or steps == L
+        reset_log.append(int(do_reset))
+        if do_reset:
+            for i in range(A):
+                bufs[i].reset()
+            env.epoch_end = (t % 2 == 0)
+            obs = env.reset()[0]
+            steps = 0
+    nz = R.Normalizer()
+    logs = np.array([nz.normalize_incremental_logscale(current_value=c, base=(L + 1) * A, increment_value=2)
+                     for c in range(0, 2 * (L + 1) * A, 2)])
+    np.savez_compressed(os.path.join(OUT, "maps.npz"), obs=np.array(obs_log), pred=np.array(pred_log),
+                        maps=np.array(maps_log), reset_after=np.array(reset_log), ra=ra, offset=offset,
+                        map_dim=np.array(bufs[0].map_dimensions), base=bufs[0].base, logscale=logs, A=A, L=L)
+    print("wrote maps.npz", np.array(maps_log).shape, "ra", repr(ra), "dims", bufs[0].map_dimensions)
+
+
+def gen_cnn():
+    """CNN Actor / Critic of algos/multiagent/NeuralNetworkCores/RADTEAM_core.py:935-1345 on one map stack
+    (the reference's Flatten(start_dim=0) only supports batch 1): state_dicts + inputs + outputs."""
+    import torch
+    from algos.multiagent.NeuralNetworkCores import RADTEAM_core as R
+    torch.manual_seed(3)
+    actor = R.Actor(map_dim=(27, 27), action_dim=8)
+    critic = R.Critic(map_dim=(27, 27))
+    xs_a = torch.rand(5, 1, 6, 27, 27)
+    xs_c = torch.rand(5, 1, 4, 27, 27)
+    with torch.no_grad():
+        probs = torch.stack([actor.actor(xs_a[i]) for i in range(5)])
+        vals = torch.stack([critic.forward(xs_c[i]) for i in range(5)])
+    out = {"xa": xs_a.numpy(), "xc": xs_c.numpy(), "probs": probs.numpy(), "vals": vals.numpy().reshape(-1)}
+    out.update({"a_" + k: v.numpy() for k, v in actor.state_dict().items()})
+    out.update({"c_" + k: v.numpy() for k, v in critic.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, "cnn.npz"), **out)
+    print("wrote cnn.npz", [k for k in out if k.startswith(("a_", "c_"))])
+
+
 def gen_round2():
     rng = np.random.default_rng(5)
     sp = np.concatenate([rng.uniform(0, 4000, 200000), rng.integers(0, 400000, 200000) / 100.0,
@@ -361,7 +432,7 @@ if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2"]
+    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn"]
     if "env" in which:
         gen_env_scenarios()
     if "gae" in which:
@@ -372,3 +443,7 @@ if __name__ == "__main__":
         gen_welford()
     if "round2" in which:
         gen_round2()
+    if "maps" in which:
+        gen_maps()
+    if "cnn" in which:
+        gen_cnn()
