@@ -226,6 +226,30 @@ typedef struct rs_update_state {
 int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
                  const double* stats, rs_update_state* state, float lr, float kl_threshold, rs_stream_t stream);
 
+/* ---- RAD-TEAM heat maps (MapsBuffer, NeuralNetworkCores/RADTEAM_core.py:395-932) ------------------------
+ * Per env the maps every agent's MapsBuffer would hold are kept ONCE (all owners see the same observations, so
+ * readings / visit counts / obstacles / combined-locations maps and the estimator state are identical across
+ * owners); the per-owner location map is a one-hot at the owner's cell and others = combined - location.
+ *   rs_maps_update  <- MapsBuffer.observation_to_map (:532-616) for every env (one call per select_action round)
+ *   rs_maps_reset   <- MapsBuffer.reset (:510-523) for the masked envs
+ *   rs_maps_stack   <- CNNBase.get_map_stack (:1791-1836): actor [N,A,6,X,Y] = {prediction, location, others,
+ *                      readings, visits, obstacles}, critic [N,4,X,Y] = {combined, readings, visits, obstacles}
+ * visit_table: float32 [(steps_per_episode+1)*A + 1], visit_table[c] = the reference's
+ * normalize_incremental_logscale(current_value = 2c, base, 2) evaluated by the caller (host Python math.log). */
+typedef struct rs_maps rs_maps;
+size_t rs_maps_state_bytes(int32_t num_envs, int32_t num_agents, int32_t steps_per_episode, int32_t map_x, int32_t map_y);
+int rs_maps_create(int32_t num_envs, int32_t num_agents, int32_t steps_per_episode, int32_t map_x, int32_t map_y,
+                   double resolution_accuracy, const float* visit_table, void* workspace, size_t workspace_bytes,
+                   rs_stream_t stream, rs_maps** out);
+void rs_maps_destroy(rs_maps* m);
+int rs_maps_reset(rs_maps* m, const uint8_t* mask, rs_stream_t stream);
+/* obs [N,A,11] float32 (the env's observation rows); pred [N,A,2] float32 scaled coordinates or NULL;
+ * mask [N] or NULL (all).  Detector cells come from the env handle's integer coordinates. */
+int rs_maps_update(rs_maps* m, rs_handle* env, const float* obs, const float* pred, const uint8_t* mask, rs_stream_t stream);
+int rs_maps_stack(rs_maps* m, float* actor_stack, float* critic_stack, rs_stream_t stream);
+/* introspection for tests: "pred_cell","cell" ([N,A] int32), "combined","readings","visits","obstacles" ([N,X*Y] f32) */
+int rs_maps_field(rs_maps* m, const char* name, void** dev_ptr, int32_t* elem_bytes, int32_t* rows, int32_t* cols);
+
 #ifdef __cplusplus
 }
 #endif

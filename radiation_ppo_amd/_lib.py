@@ -74,6 +74,15 @@ SYMBOLS = [
                               C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rs_adam_step", C.c_int, [C.POINTER(RsMlpParams), C.POINTER(RsMlpParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    ("rs_maps_state_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("rs_maps_create", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("rs_maps_destroy", None, [C.c_void_p]),
+    ("rs_maps_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rs_maps_update", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rs_maps_stack", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rs_maps_field", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32)]),
     ("rs_gae", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                          C.c_int32, C.c_double, C.c_double, C.c_void_p]),
 ]

@@ -11,7 +11,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librs_hip.so")
 
-SOURCES = ["rs_env.hip", "rs_ppo.hip"]
+SOURCES = ["rs_env.hip", "rs_ppo.hip", "rs_maps.hip"]
 # -ffp-contract=off: float64 env arithmetic must round like the reference's Python floats (no FMA fusing)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
