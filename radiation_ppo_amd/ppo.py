@@ -430,7 +430,7 @@ class Collector:
             self.ep_ret += r_used
             self.steps_in_ep += 1
             oob_count += info["out_of_bounds"].int()
-            terminal = done.any(dim=1)                                       # train.py:387-391
+            terminal = done.bool().any(dim=1)                                       # train.py:387-391
             done_count += terminal.int()
             timeout = self.steps_in_ep == L                                  # train.py:394-405
             episode_over = terminal | timeout

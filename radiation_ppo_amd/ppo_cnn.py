@@ -1,0 +1,256 @@
+"""RAD-TEAM (CNN) PPO on the device: multi-agent collector over the K5 heat maps and the CNN update.
+
+Mirrors (paths relative to the reference root):
+  CNNCollector      <- the epoch loop of algos/multiagent/train.py:332-548 with CNNBase.select_action
+                       (NeuralNetworkCores/RADTEAM_core.py:1838-1892) for every agent of every env
+  CNNAgentPPO       <- AgentPPO, 'cnn' branch (algos/multiagent/ppo.py:620-642, :815-897): actor loss
+                       -mean(min(r A, clip(r) A)) (:966-997) with KL early stop at 1.5*target_kl, then train_v_iters
+                       critic MSE steps (:1020-1045); sample() draws all indexes below the summed length of the
+                       COMPLETE episodes (:754-764); separate Adam + StepLR(100, 0.99) for actor and critic;
+                       with a global critic only agent 0 updates it (:858)
+The location-prediction map (PFGRU) is not built: channel 0 stays empty unless the caller
+supplies predictions.
+"""
+from typing import Any, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .envs import RadSearchVec
+from .maps import CNNActor, CNNCritic, HeatMaps
+from .ppo import RolloutBuffer, UpdateResult, _world, normalize_advantages
+
+
+class CNNAgentPPO:
+    def __init__(self, id: int, map_dim=(27, 27), action_space: int = 8, train_pi_iters: int = 40, train_v_iters: int = 40,
+                 actor_learning_rate: float = 3e-4, critic_learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 0.0,
+                 clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, GlobalCritic: Optional[CNNCritic] = None,
+                 GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 32768, **unused: Any):
+        self.id = id
+        self.device = torch.device(device)
+        self.gamma, self.lam, self.alpha = gamma, lam, alpha
+        self.clip_ratio, self.target_kl = clip_ratio, target_kl
+        self.train_pi_iters, self.train_v_iters = train_pi_iters, train_v_iters
+        self.pi = CNNActor(map_dim=map_dim, action_dim=action_space).to(self.device)
+        self.global_critic = GlobalCritic is not None
+        self.critic = GlobalCritic if GlobalCritic is not None else CNNCritic(map_dim=map_dim).to(self.device)
+        self.pi_optimizer = torch.optim.Adam(self.pi.parameters(), lr=actor_learning_rate)
+        self.critic_optimizer = GlobalCriticOptimizer if GlobalCriticOptimizer is not None else torch.optim.Adam(
+            self.critic.parameters(), lr=critic_learning_rate)
+        self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)
+        self.critic_scheduler = torch.optim.lr_scheduler.StepLR(self.critic_optimizer, step_size=100, gamma=0.99)
+        self.chunk = chunk
+
+    @staticmethod
+    def _allreduce(params) -> None:
+        if _world() == 1:
+            return
+        ps = [p for p in params if p.grad is not None]
+        flat = torch.cat([p.grad.view(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for p in ps:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def sync_params(self) -> None:
+        if _world() > 1:
+            for mod in (self.pi, self.critic):
+                flat = torch.cat([p.data.view(-1) for p in mod.parameters()])
+                dist.broadcast(flat, src=0)
+                o = 0
+                for p in mod.parameters():
+                    p.data.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
+
+    @torch.no_grad()
+    def act(self, actor_stack: torch.Tensor, critic_stack: torch.Tensor, u: torch.Tensor):
+        logp_all = torch.log_softmax(self.pi.logits(actor_stack), dim=-1)
+        cdf = torch.cumsum(logp_all.exp(), dim=-1)
+        a = (cdf <= u.unsqueeze(-1)).sum(dim=-1).clamp_(max=logp_all.shape[-1] - 1)
+        logp = logp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1)
+        return a, logp, self.critic(critic_stack)
+
+    def update_agent(self, actor_in, critic_in, act, adv, ret, logp_old, w, update_critic: bool) -> UpdateResult:
+        """actor_in(lo, hi) / critic_in(lo, hi) return the map stacks of samples [lo, hi); w sums to 1 over the global batch."""
+        M = act.shape[0]
+        thr = 1.5 * self.target_kl
+        kk, kl_reached, last = 0, False, None
+        while not kl_reached and kk < self.train_pi_iters:                      # ppo.py:825-846
+            self.pi_optimizer.zero_grad(set_to_none=True)
+            stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+            for lo in range(0, M, self.chunk):
+                hi = min(lo + self.chunk, M)
+                logp_all = torch.log_softmax(self.pi.logits(actor_in(lo, hi)), dim=-1)
+                logp = logp_all.gather(-1, act[lo:hi].unsqueeze(-1)).squeeze(-1)
+                ratio = torch.exp(logp - logp_old[lo:hi])
+                clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv[lo:hi]
+                loss = -(w[lo:hi] * torch.min(ratio * adv[lo:hi], clip_adv)).sum()      # ppo.py:984-988
+                loss.backward()
+                with torch.no_grad():
+                    ent = -(logp_all.exp() * logp_all).sum(-1)
+                    clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
+                    stats += torch.stack([(w[lo:hi] * (logp_old[lo:hi] - logp)).sum(), (w[lo:hi] * ent).sum(),
+                                          (w[lo:hi] * clipped.float()).sum(), loss.detach()]).double()
+            if _world() > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            last = stats.tolist()
+            if last[0] < thr:                                                   # ppo.py:838-845
+                self._allreduce(self.pi.parameters())
+                self.pi_optimizer.step()
+            else:
+                kl_reached = True
+            kk += 1
+        self.pi_scheduler.step()
+        loss_c = float("nan")
+        if update_critic:                                                       # ppo.py:858-873
+            for _ in range(self.train_v_iters):
+                self.critic_optimizer.zero_grad(set_to_none=True)
+                tot = torch.zeros((), dtype=torch.float64, device=self.device)
+                for lo in range(0, M, self.chunk):
+                    hi = min(lo + self.chunk, M)
+                    v = self.critic(critic_in(lo, hi))
+                    lc = (w[lo:hi] * (v - ret[lo:hi]) ** 2).sum()               # MSE (ppo.py:1040-1045)
+                    lc.backward()
+                    tot += lc.detach().double()
+                if _world() > 1:
+                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                self._allreduce(self.critic.parameters())
+                self.critic_optimizer.step()
+                loss_c = float(tot.item())
+            self.critic_scheduler.step()
+        return UpdateResult(stop_iteration=kk, loss_policy=last[3], loss_critic=loss_c, loss_predictor=0.0, kl_divergence=last[0],
+                            Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
+
+    def save(self, path: str) -> None:
+        torch.save({"actor": self.pi.state_dict(), "critic": self.critic.state_dict()}, path)
+
+
+class CNNCollector:
+    """Multi-agent RAD-TEAM collector: heat maps (K5) -> CNN actors/critic -> env lock-step -> buffer."""
+
+    def __init__(self, env: RadSearchVec, agents: Dict[int, CNNAgentPPO], steps_per_epoch: int, steps_per_episode: int,
+                 global_critic_flag: bool = True):
+        self.env, self.agents = env, agents
+        self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, env.number_agents
+        self.team_reward = global_critic_flag
+        dev = env.device
+        self.maps = HeatMaps(env, steps_per_episode, enforce_boundaries=bool(env.cfg.enforce_grid_boundaries))
+        X, Y = self.maps.map_dimensions
+        self.buf = RolloutBuffer(self.T, self.N, self.A, _lib.RS_OBS_DIM, dev)
+        # per step only the four shared maps and the cell indices are stored; actor stacks are rebuilt on demand
+        self.shared = torch.zeros(self.T, self.N, 4, X, Y, dtype=torch.float32, device=dev)
+        self.cells = torch.zeros(self.T, self.N, self.A, dtype=torch.int64, device=dev)
+        self.pcells = torch.zeros(self.T, self.N, self.A, dtype=torch.int64, device=dev)
+        self.steps_in_ep = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.ep_ret = torch.zeros(self.N, self.A, dtype=torch.float32, device=dev)
+        self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
+        self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
+        self.complete_len = torch.zeros(self.N, dtype=torch.int64, device=dev)
+        self.obs = None
+
+    def start(self) -> None:
+        obs, *_ = self.env.reset()
+        self.obs = obs.clone()
+
+    def actor_stack_from(self, shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
+        """CNNBase.get_map_stack (:1791-1836) for owner a from the stored shared maps: [B,6,X,Y]."""
+        B, _, X, Y = shared.shape
+        loc = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
+        loc.scatter_(1, cells[:, a:a + 1], 1.0)
+        pm = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
+        pc = pcells[:, a:a + 1]
+        pm.scatter_(1, pc.clamp(min=0), (pc >= 0).float())
+        loc = loc.view(B, 1, X, Y)
+        return torch.cat([pm.view(B, 1, X, Y), loc, shared[:, 0:1] - loc, shared[:, 1:4]], dim=1)
+
+    @torch.no_grad()
+    def _policy(self, t: Optional[int]):
+        """One select_action round for every agent (maps updated once per round, as every owner's MapsBuffer is)."""
+        self.maps.update(self.obs)
+        actor, critic = self.maps.stacks()
+        return actor, critic
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        if self.obs is None:
+            self.start()
+        env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
+        dev = env.device
+        done_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        oob_count = torch.zeros(N, A, dtype=torch.int32, device=dev)
+        ep_ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        ep_len_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        ep_cnt = torch.zeros((), dtype=torch.float64, device=dev)
+        self.complete_len.zero_()
+        for t in range(T):
+            actor, critic = self._policy(t)
+            self.shared[t] = critic
+            self.cells[t] = self.maps.field("cell").long()
+            self.pcells[t] = self.maps.field("pred_cell").long()
+            env.action_uniforms(self._u)
+            for a, ag in self.agents.items():
+                act, logp, v = ag.act(actor[:, a], critic, self._u[:, a])
+                buf.act[t, :, a] = act
+                buf.logp[t, :, a] = logp
+                buf.val[t, :, a] = v
+                self._act8[:, a] = act.to(torch.int8)
+            buf.obs[t] = self.obs
+            next_obs, rew, team, done, info = env.step(self._act8)
+            r_used = team.unsqueeze(1).expand(N, A) if self.team_reward else rew
+            buf.rew[t] = r_used
+            self.ep_ret += r_used
+            self.steps_in_ep += 1
+            oob_count += info["out_of_bounds"].int()
+            terminal = done.bool().any(dim=1)
+            done_count += terminal.int()
+            timeout = self.steps_in_ep == L
+            episode_over = terminal | timeout
+            epoch_ended = t == T - 1
+            cut = episode_over | epoch_ended
+            boot = timeout | epoch_ended
+            buf.cut[t] = cut.unsqueeze(1).to(torch.uint8).expand(N, A)
+            self.obs = next_obs.clone()
+            # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480);
+            # the maps of those envs see the final observation a second time, exactly as in the reference
+            self.maps.update(self.obs, mask=boot & cut)
+            actor_b, critic_b = self.maps.stacks()
+            for a, ag in self.agents.items():
+                vb = ag.critic(critic_b)
+                buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
+            ep_ret_sum += (self.ep_ret[:, 0].double() * episode_over).sum()
+            ep_len_sum += (self.steps_in_ep.double() * episode_over).sum()
+            ep_cnt += episode_over.double().sum()
+            self.complete_len = torch.where(episode_over, torch.full_like(self.complete_len, t + 1), self.complete_len)
+            if epoch_ended:
+                env.set_epoch_end()
+            self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
+            obs_r, *_ = env.reset(cut)
+            self.obs = obs_r.clone()
+            self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
+            self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
+        buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return dict(DoneCount=done_count.sum(), OutOfBound=oob_count.sum(), EpRetSum=ep_ret_sum, EpLenSum=ep_len_sum,
+                    EpCount=ep_cnt)
+
+    def update(self) -> Dict[int, UpdateResult]:
+        buf, T, N = self.buf, self.T, self.N
+        X, Y = self.maps.map_dimensions
+        n_total = N * _world()
+        # sample() (ppo.py:754-764): every index below the summed length of the complete episodes of the rank
+        tt = torch.arange(T, device=buf.rew.device).view(T, 1)
+        valid = tt < self.complete_len.view(1, N)
+        w = (valid.float() / (self.complete_len.clamp(min=1).view(1, N).float() * n_total)).reshape(-1)
+        shared = self.shared.view(T * N, 4, X, Y)
+        cells = self.cells.view(T * N, self.A)
+        pcells = self.pcells.view(T * N, self.A)
+        out = {}
+        for a, ag in self.agents.items():
+            adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
+            actor_in = lambda lo, hi, a=a: self.actor_stack_from(shared[lo:hi], cells[lo:hi], pcells[lo:hi], a)
+            critic_in = lambda lo, hi: shared[lo:hi]
+            upd_c = (not ag.global_critic) or a == 0
+            out[a] = ag.update_agent(actor_in, critic_in, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
+                                     buf.logp[:, :, a].reshape(-1), w, update_critic=upd_c)
+        return out

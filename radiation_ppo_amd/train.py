@@ -20,6 +20,8 @@ import torch.distributed as dist
 
 from .envs import RadSearch, RadSearchVec
 from .ppo import Collector, FusedCollector, VecAgentPPO
+from .ppo_cnn import CNNAgentPPO, CNNCollector
+from .maps import CNNCritic
 
 # progress.txt columns of the reference (train.py:605-627) + throughput columns of this build
 COLUMNS = ["AgentID", "Epoch", "AverageVVals", "StdVVals", "MaxVVals", "MinVVals", "TotalEnvInteracts", "loss_policy",
@@ -76,9 +78,10 @@ class train_PPO:
     def __post_init__(self) -> None:
         if self.actor_critic_architecture != "cnn" and self.global_critic_flag:
             raise ValueError("Global critic not supported in RAD-A2C")        # train.py:157-160
-        if self.actor_critic_architecture not in ("ff", "mlp"):
-            raise NotImplementedError(f"architecture {self.actor_critic_architecture!r}: only the 2x64 MLP path "
-                                      "('ff', alias 'mlp') is built (SURVEY.md section 8, notes N4/N7)")
+        if self.actor_critic_architecture not in ("ff", "mlp", "cnn"):
+            raise NotImplementedError(f"architecture {self.actor_critic_architecture!r}: the 2x64 MLP path ('ff', alias "
+                                      "'mlp') and the RAD-TEAM CNN path ('cnn') are built; the GRU/PFGRU cores are SURVEY.md "
+                                      "section 8 rows f1/f2")
         if self.render or self.save_gif:
             raise NotImplementedError("rendering is outside the hot path")
         if self.seed:
@@ -99,6 +102,20 @@ class train_PPO:
         kw.setdefault("steps_per_epoch", self.steps_per_epoch)
         kw.setdefault("steps_per_episode", self.steps_per_episode)
         kw.setdefault("number_of_agents", self.number_of_agents)
+        if self.actor_critic_architecture == "cnn":
+            gc = gco = None
+            if self.global_critic_flag:                                        # train.py:191-206
+                gc = CNNCritic().to(self.vec.device)
+                gco = torch.optim.Adam(gc.parameters(), lr=kw.get("critic_learning_rate", 1e-3))
+            kw.pop("GlobalCriticOptimizer", None)
+            self.agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, device=self.vec.device, **kw)
+                           for i in range(self.number_of_agents)}
+            for ag in self.agents.values():
+                ag.sync_params()
+            self.collector = CNNCollector(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
+                                          global_critic_flag=self.global_critic_flag)
+            self.start_time = time.time()
+            return
         self.agents = {i: VecAgentPPO(id=i, actor_critic_architecture=self.actor_critic_architecture,
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}
         for ag in self.agents.values():

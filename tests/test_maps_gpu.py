@@ -79,3 +79,79 @@ def test_cnn_modules_match_reference_outputs(golden_dir):
     assert np.allclose(probs, g["probs"], rtol=1e-4, atol=1e-5)
     assert np.allclose(vals, g["vals"], rtol=1e-4, atol=1e-5)
     assert sum(p.numel() for p in actor.parameters()) == 88832 and sum(p.numel() for p in critic.parameters()) == 88569
+
+
+def test_cnn_train_entry_point_multiagent_global_critic():
+    """train_PPO(actor_critic_architecture='cnn', global_critic_flag=True) -- the reference's defaults
+    (train.py:119-121) -- runs collector + update for 2 agents; stored stacks rebuild exactly; losses finite."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.train import train_PPO
+    env = RadSearchVec(16, number_agents=2, obstruction_count=2, enforce_grid_boundaries=True, seed=5)
+    sim = train_PPO(env=env, logger_kwargs={}, ppo_kwargs=dict(steps_per_epoch=24, steps_per_episode=8, number_of_agents=2,
+                                                               train_pi_iters=3, train_v_iters=3, alpha=0.1),
+                    seed=5, number_of_agents=2, actor_critic_architecture="cnn", global_critic_flag=True,
+                    steps_per_epoch=24, steps_per_episode=8, total_epochs=2)
+    assert sim.agents[0].critic is sim.agents[1].critic          # train.py:228-232
+    sim.train()
+    col = sim.collector
+    # the actor stack rebuilt from (shared maps, cells) equals what the kernel produced at collection time
+    col.maps.update(col.obs)
+    actor, critic = col.maps.stacks()
+    cells = col.maps.field("cell").long()
+    pc = col.maps.field("pred_cell").long()
+    for a in range(2):
+        rebuilt = col.actor_stack_from(critic, cells, pc, a)
+        assert torch.equal(rebuilt, actor[:, a])
+    rows = sim.loggers[0].rows
+    assert len(rows) == 2 and all(np.isfinite(r["loss_policy"]) and np.isfinite(r["loss_critic"]) for r in rows)
+    assert np.isnan(sim.loggers[1].rows[0]["loss_critic"])        # only agent 0 updates the global critic (ppo.py:858)
+
+
+def test_cnn_collector_replays_through_oracles():
+    """One epoch of the multi-agent CNN collector, replayed with the env oracle + the MapsBuffer oracle following
+    the reference loop (train.py:332-548): select_action round -> env.step -> bootstrap round on timeout/epoch cut
+    (the maps see the last observation twice) -> MapsBuffer.reset + env.reset.  Stored shared maps, cells, rewards
+    and cuts must be reproduced exactly."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L, obst = 24, 2, 30, 9, 3
+    torch.manual_seed(2)
+    env = RadSearchVec(N, number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True, seed=SEED)
+    gc = CNNCritic().cuda()
+    gco = torch.optim.Adam(gc.parameters(), lr=1e-3)
+    agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=2, train_v_iters=2) for i in range(A)}
+    col = CNNCollector(env, agents, T, L, global_critic_flag=True)
+    col.collect()
+    buf = col.buf
+    act, rew, cut = (x.cpu().numpy() for x in (buf.act, buf.rew, buf.cut))
+    shared, cells = col.shared.cpu().numpy(), col.cells.cpu().numpy()
+    for n in range(0, N, 4):
+        e = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True)
+        mb = MapsOracle(steps_per_episode=L, number_of_agents=A)
+        o = e._ret[0]
+        steps = 0
+        for t in range(T):
+            od = {i: np.array(o[i], dtype=np.float64) for i in range(A)}
+            m = mb.observation_to_map(od, 0, (0.0, 0.0))
+            exp = np.stack([mb.combined, mb.readings_map, mb.visits, mb.obstacles])
+            assert np.array_equal(shared[t, n], exp), (n, t)
+            for i in range(A):
+                assert cells[t, n, i] == mb.last_coords[i][0] * 27 + mb.last_coords[i][1]
+            ro, rr, rd, _ = e.step({i: int(act[t, n, i]) for i in range(A)})
+            assert rew[t, n, 0] == np.float32(rr["team_reward"]), (n, t)
+            steps += 1
+            o = ro
+            over = any(rd.values()) or steps == L
+            expect_cut = over or t == T - 1
+            assert bool(cut[t, n, 0]) == expect_cut, (n, t)
+            if expect_cut:
+                if steps == L or t == T - 1:
+                    mb.observation_to_map({i: np.array(o[i], dtype=np.float64) for i in range(A)}, 0, (0.0, 0.0))
+                if t == T - 1:
+                    e.epoch_end = True
+                mb.reset()
+                o = e.reset()[0]
+                steps = 0
+    res = col.update()
+    assert np.isfinite(res[0].loss_policy) and np.isfinite(res[0].loss_critic)
