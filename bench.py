@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 K1_BYTES_PER_AGENT_STEP = 157
 
 
-def _cpu_worker(args):
+def _py_worker(args):
     wid, n_envs, seconds = args
     import random
     from oracle.radsearch_oracle import PhiloxDraws, RadSearchOracle
@@ -60,20 +60,45 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
+def _c_lib():
+    import ctypes as C
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_build", "librs_oracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = C.CDLL(so)
+    lib.rso_bench.restype = C.c_long
+    lib.rso_bench.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_long, C.c_int]
+    return lib
+
+
+def _c_worker(args):
+    wid, n_envs, target = args
+    lib = _c_lib()
+    t0 = time.perf_counter()
+    n = lib.rso_bench(SEED, wid * n_envs, n_envs, target, L_EPISODE)
+    return abs(n), time.perf_counter() - t0
+
+
 def cpu_baseline(seconds: float = 10.0):
-    """The oracle (kind "port": a line-for-line Python restatement of the reference's RadSearch.step/reset)
-    on the host cores: one process per core, 16 envs each, uniform random actions, ~`seconds` of work."""
+    """The oracle on the host cores (kind "port"): the C restatement of the reference's RadSearch.step/reset
+    (oracle/radsearch_oracle.c, pinned to the Python oracle and through it to the reference's golden vectors), one
+    process per core, 16 obstacle-free single-agent envs each, uniform random actions, ~`seconds` of work per core.
+    The pure-Python oracle (closest to the reference's own Python env.step) is timed on one core beside it."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
-    one = _cpu_worker((0, 16, min(seconds, 5.0)))
+    probe = _c_worker((0, 16, 2_000_000))
+    rate = probe[0] / probe[1]
+    target = int(rate * seconds)
     with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(w, 16, seconds) for w in range(cores)])
+        res = pool.map(_c_worker, [(w, 16, target) for w in range(cores)])
     total = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
+    py = _py_worker((0, 16, min(seconds, 4.0)))
     return {"value": total / wall, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "single_core_value": one[0] / one[1],
-            "sample": f"{cores} procs x 16 obstacle-free single-agent envs, uniform random actions, {seconds:.0f} s each "
-                      f"(oracle/radsearch_oracle.py)"}
+            "single_core_value": rate, "python_port_single_core_value": py[0] / py[1],
+            "sample": f"{cores} procs x 16 obstacle-free single-agent envs, uniform random actions, {target} env steps "
+                      f"(~{seconds:.0f} s) each, oracle/radsearch_oracle.c (-O2, scalar); env step + reset only, no policy"}
 
 
 def time_step_kernel(env, reps: int = 400):
