@@ -249,7 +249,7 @@ def main():
         if args.collector == "fused":
             g_ms, g_m = time_grad_pass(col)
             tfl = PPO_GRAD_FLOPS_PER_SAMPLE * g_m / (g_ms * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad_kernel<8> + rs_ppo_grad_kernel<1> (+ rs_ppo_reduce_kernel)",
+            result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad2_kernel<8> + rs_ppo_grad2_kernel<1> (+ rs_ppo_reduce_kernel)",
                                   "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
                                   "traffic": None, "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
                                   "avg_launch_ms": g_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}

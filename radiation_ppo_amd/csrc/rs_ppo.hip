@@ -223,6 +223,8 @@ __global__ void __launch_bounds__(64) rs_rollout_kernel(RsParams P, RsMlpParams 
 }
 
 
+#include "rs_rollout16.hpp"
+
 // ------------------------------------------------------------------------------------------------
 // K7: fused PPO loss + gradients for one FF_core network (NOUT = 8: actor, NOUT = 1: critic).
 //
@@ -680,16 +682,24 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
                rs_stream_t stream) {
     if (!h || !actor || !critic || !args) return RS_ERR_INVALID_ARG;
     const RsParams& P = h->P;
-    if (P.A != 1 || (P.N % RS_WAVE) != 0) return RS_ERR_UNSUPPORTED;
+    if (P.A != 1 || (P.N % 16) != 0) return RS_ERR_UNSUPPORTED;
     const bool has_obs = P.obstruction_count != 0;
     if (has_obs && P.group != 1) return RS_ERR_UNSUPPORTED;
     if (args->steps_per_epoch < 1 || args->steps_per_episode < 1) return RS_ERR_INVALID_ARG;
-    size_t lds = sizeof(float) * (size_t)(rs_mlp_lds_floats(8) + rs_mlp_lds_floats(1)) + 16;
+    static int ver = -1;
+    if (ver < 0) { const char* e = getenv("RS_ROLLOUT_V"); ver = (e && e[0] == '1') ? 1 : 2; }
+    const bool v2 = ver == 2 || (P.N % RS_WAVE) != 0;          // v2: 16 envs per wave (256 waves at 4096 envs)
+    size_t lds = sizeof(float) * (size_t)(v2 ? (rs_mlp16_lds_floats(8) + rs_mlp16_lds_floats(1)) : (rs_mlp_lds_floats(8) + rs_mlp_lds_floats(1))) + 16;
     lds += (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
     lds += RS_WAVE * RS_OBS_DIM * 4 + RS_WAVE * 4 + 2 * RS_WAVE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (has_obs) hipLaunchKernelGGL(rs_rollout_kernel<true>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
-    else hipLaunchKernelGGL(rs_rollout_kernel<false>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    if (v2) {
+        if (has_obs) hipLaunchKernelGGL(rs_rollout16_kernel<true>, dim3(P.N / 16), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+        else hipLaunchKernelGGL(rs_rollout16_kernel<false>, dim3(P.N / 16), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    } else {
+        if (has_obs) hipLaunchKernelGGL(rs_rollout_kernel<true>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+        else hipLaunchKernelGGL(rs_rollout_kernel<false>, dim3(P.N / RS_WAVE), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    }
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

@@ -52,6 +52,13 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
     }
     dbl[lane] = 0.0f;
     __syncthreads();
+    // layer-1 fragments with the bias in the padded input column k = 11 (k-step 5, upper lane half)
+    float* w1b = W.w1f;
+    for (int i = threadIdx.x; i < 2 * 32; i += blockDim.x) {
+        const int it = i >> 5, row = i & 31;
+        w1b[(it * 6 + 5) * 64 + 32 + row] = W.b1[32 * it + row];
+    }
+    __syncthreads();
 
     const int M = B.M;
     const int groups = (M + 31) / 32;
@@ -79,7 +86,7 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         float x[RS_IN_PAD];
 #pragma unroll
         for (int k = 0; k < RS_IN; ++k) x[k] = B.x[(size_t)mm * RS_IN + k];
-        x[11] = 0.0f;
+        x[11] = 1.0f;                     // constant input: column 11 of w1b carries b1, and column 11 of dW1 is db1
         const float wi = valid ? B.w[mm] : 0.0f;
 
         // ---------------- forward ----------------
@@ -87,14 +94,14 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) H1[it][r] = W.b1[32 * it + rs_kappa(r, h)];
+            for (int r = 0; r < 16; ++r) H1[it][r] = 0.0f;
         {
-            float a0 = W.w1f[(0 * 6 + 0) * 64 + lane], a1 = W.w1f[(1 * 6 + 0) * 64 + lane];
+            float a0 = w1b[(0 * 6 + 0) * 64 + lane], a1 = w1b[(1 * 6 + 0) * 64 + lane];
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const float b = h ? x[2 * s + 1] : x[2 * s];
                 float n0 = 0.f, n1 = 0.f;
-                if (s + 1 < 6) { n0 = W.w1f[(0 * 6 + s + 1) * 64 + lane]; n1 = W.w1f[(1 * 6 + s + 1) * 64 + lane]; }
+                if (s + 1 < 6) { n0 = w1b[(0 * 6 + s + 1) * 64 + lane]; n1 = w1b[(1 * 6 + s + 1) * 64 + lane]; }
                 H1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, H1[0], 0, 0, 0);
                 H1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, H1[1], 0, 0, 0);
                 a0 = n0; a1 = n1;
@@ -132,11 +139,17 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             float p = 0.0f;
-            const float* w = W.w3h + (h * NOUT + o) * 32;
+            const float4* w = reinterpret_cast<const float4*>(W.w3h + (h * NOUT + o) * 32);   // 16-byte aligned rows
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p = fmaf(w[kt * 16 + r], H2[kt][r], p);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 wv = w[kt * 4 + r4];
+                    p = fmaf(wv.x, H2[kt][4 * r4 + 0], p);
+                    p = fmaf(wv.y, H2[kt][4 * r4 + 1], p);
+                    p = fmaf(wv.z, H2[kt][4 * r4 + 2], p);
+                    p = fmaf(wv.w, H2[kt][4 * r4 + 3], p);
+                }
             // fixed summation order in both lanes: (half 0) + (half 1)
             const float q = __shfl_xor(p, 32);
             out[o] = (h ? (q + p) : (p + q)) + W.b3[o];

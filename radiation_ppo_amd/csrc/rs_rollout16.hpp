@@ -1,0 +1,260 @@
+// rs_rollout16.hpp -- K6 v2: the fused collector with 16 envs per wave.
+//
+// v1 (rs_rollout_kernel) gives a wave 64 envs: 4096 envs are 64 waves on 64 of the 256 CUs, and every lock-step
+// pays 304 MFMAs of 64 cycles on one SIMD.  v2 gives a wave 16 envs: 256 waves (every CU busy), the MLP runs on
+// v_mfma_f32_16x16x4_f32 tiles (152 MFMAs of 32 cycles per lock-step), and the env step -- a latency-bound scalar
+// f64 chain whose cost does not depend on how many lanes run it -- is paid once per 16 envs on 4x as many CUs.
+//
+// Lane mapping: lane l = (j = l&15, g = l>>4).  Env slot j of the wave is env n = 16*block + j; its state and all
+// per-env logic live in lane (j, 0).  For the MLP the four lanes (j, 0..3) share sample j:
+//   A lane l: W[16it + (l&15)][k = 4s + (l>>4)]     B lane l: In[k = 4s + (l>>4)][sample l&15]
+//   D lane l, reg q: sample l&15, unit 16it + 4*(l>>4) + q
+// so the k-step (ut, q) of the next layer consumes unit 16ut + 4g + q straight from the accumulator registers
+// (the 16x16 analogue of the kappa trick in rs_mlp.hpp).
+#pragma once
+#include "rs_mlp.hpp"
+
+__host__ __device__ constexpr int rs_mlp16_lds_floats(int nout) { return 4 * 3 * 64 + 4 * 16 * 64 + 64 + 4 * nout * 16 + nout; }
+
+template <int NOUT>
+struct RsMlp16 {
+    float* w1f;   // [4 it][3 s][64]   2log2e * W1[16it + (l&15)][4s + (l>>4)], column 11 = 2log2e * b1 (x[11] := 1)
+    float* w2f;   // [4 it][16 ks][64] 2log2e * W2[16it + (l&15)][16ut + 4(l>>4) + q], ks = 4ut + q
+    float* b2;    // [64] 2log2e * b2
+    float* w3g;   // [4 g][NOUT][16]   W3[o][16ut + 4g + q]
+    float* b3;    // [NOUT]
+    __device__ __forceinline__ void carve(float* base) {
+        w1f = base; w2f = w1f + 4 * 3 * 64; b2 = w2f + 4 * 16 * 64; w3g = b2 + 64; b3 = w3g + 4 * NOUT * 16;
+    }
+    __device__ __forceinline__ void fill(const RsMlpParams& p) {
+        const int tid = threadIdx.x, nt = blockDim.x;
+        for (int i = tid; i < 4 * 3 * 64; i += nt) {
+            const int l = i & 63, s = (i >> 6) % 3, it = i / (3 * 64);
+            const int row = 16 * it + (l & 15), k = 4 * s + (l >> 4);
+            w1f[i] = RS_TANH_PRESCALE * ((k < RS_IN) ? p.w1[row * RS_IN + k] : p.b1[row]);
+        }
+        for (int i = tid; i < 4 * 16 * 64; i += nt) {
+            const int l = i & 63, ks = (i >> 6) & 15, it = i >> 10;
+            const int unit = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);
+            w2f[i] = RS_TANH_PRESCALE * p.w2[(16 * it + (l & 15)) * RS_HID + unit];
+        }
+        for (int i = tid; i < 64; i += nt) b2[i] = RS_TANH_PRESCALE * p.b2[i];
+        for (int i = tid; i < 4 * NOUT * 16; i += nt) {
+            const int q16 = i & 15, o = (i >> 4) % NOUT, g = i / (16 * NOUT);
+            w3g[i] = p.w3[o * RS_HID + 16 * (q16 >> 2) + 4 * g + (q16 & 3)];
+        }
+        for (int i = tid; i < NOUT; i += nt) b3[i] = p.b3[i];
+    }
+    // forward for the wave's 16 samples; xs[k] = input k of sample (lane&15), already broadcast to the 4 lanes
+    __device__ __forceinline__ void forward(const float (&xs)[RS_IN_PAD], float (&out)[NOUT]) const {
+        const int lane = threadIdx.x & 63, g = lane >> 4;
+        f32x4 H1[4], H2[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { H1[it][q] = 0.0f; H2[it][q] = b2[16 * it + 4 * g + q]; }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float b = (g == 0) ? xs[4 * s] : (g == 1) ? xs[4 * s + 1] : (g == 2) ? xs[4 * s + 2] : xs[4 * s + 3];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                H1[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[(it * 3 + s) * 64 + lane], b, H1[it], 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) H1[it][q] = rs_tanh_scaled(H1[it][q]);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float b = H1[ks >> 2][ks & 3];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                H2[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[(it * 16 + ks) * 64 + lane], b, H2[it], 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) H2[it][q] = rs_tanh_scaled(H2[it][q]);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float4* w = reinterpret_cast<const float4*>(w3g + (g * NOUT + o) * 16);
+            float p = 0.0f;
+#pragma unroll
+            for (int ut = 0; ut < 4; ++ut) {
+                const float4 wv = w[ut];
+                p = fmaf(wv.x, H2[ut][0], p); p = fmaf(wv.y, H2[ut][1], p);
+                p = fmaf(wv.z, H2[ut][2], p); p = fmaf(wv.w, H2[ut][3], p);
+            }
+            // fixed-order tree over the four lanes of the sample: (g0 + g1) + (g2 + g3) in every lane
+            const float q1 = __shfl_xor(p, 16);
+            const float s01 = (g & 1) ? (q1 + p) : (p + q1);
+            const float q2 = __shfl_xor(s01, 32);
+            out[o] = ((g & 2) ? (q2 + s01) : (s01 + q2)) + b3[o];
+        }
+    }
+};
+
+// broadcast the inputs of sample j (held by lane (j, 0)) to its four lanes
+__device__ __forceinline__ void rs_bcast_x16(const float (&xo)[RS_IN_PAD], float (&xs)[RS_IN_PAD]) {
+    const int src = threadIdx.x & 15;
+#pragma unroll
+    for (int k = 0; k < RS_IN_PAD; ++k) xs[k] = __shfl(xo[k], src);
+}
+
+template <bool HAS_OBS>
+__global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParams pa, RsMlpParams pc, rs_rollout_args R) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* wts = reinterpret_cast<float*>(smem);
+    unsigned char* p = smem + sizeof(float) * (size_t)(rs_mlp16_lds_floats(8) + rs_mlp16_lds_floats(1));
+    p = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~uintptr_t(15));
+    int* lds_geo = reinterpret_cast<int*>(p);
+    uint32_t* lds_adj = reinterpret_cast<uint32_t*>(p + RS_MAX_VERT * RS_WAVE * 4);
+    double* lds_d = reinterpret_cast<double*>(p + 2 * RS_MAX_VERT * RS_WAVE * 4);
+    float* tile = reinterpret_cast<float*>(p + (HAS_OBS ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0));
+    float* lds_rew = tile + RS_WAVE * RS_OBS_DIM;
+    uint8_t* lds_done = reinterpret_cast<uint8_t*>(lds_rew + RS_WAVE);
+    uint8_t* lds_oob = lds_done + RS_WAVE;
+
+    RsMlp16<8> ACT; RsMlp16<1> CRT;
+    ACT.carve(wts);
+    CRT.carve(wts + rs_mlp16_lds_floats(8));
+    ACT.fill(pa); CRT.fill(pc);
+
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const bool own = lane < 16;                                   // lane (j, 0) owns env slot j
+    const int n = blockIdx.x * 16 + j;                            // N % 16 == 0 (checked by the host)
+    const int N = P.N, T = R.steps_per_epoch, L = R.steps_per_episode;
+    RsGeo g{lds_geo, 0, 0, 0};
+    if (HAS_OBS) rs_load_geo(P, n, own, lds_geo, g);
+    __syncthreads();
+
+    float oraw[RS_OBS_DIM];
+#pragma unroll
+    for (int k = 0; k < RS_OBS_DIM; ++k) oraw[k] = R.cur_obs[(size_t)n * RS_OBS_DIM + k];
+    RsWelford W{R.w_count[n], R.w_mean[n], R.w_sq[n], R.w_std[n]};
+    int steps = R.steps_in_ep[n];
+    float ep_ret = R.ep_ret[n];
+    int done_count = 0, oob_count = 0, ep_count = 0;
+    double ep_ret_sum = 0.0, ep_len_sum = 0.0;
+    const uint32_t k0 = P.seed, k1 = P.env_id_base + (uint32_t)n;
+
+    float xo[RS_IN_PAD], xs[RS_IN_PAD];
+#pragma unroll
+    for (int k = 0; k < RS_OBS_DIM; ++k) xo[k] = oraw[k];
+    xo[0] = W.standardize(oraw[0]);
+    xo[11] = 1.0f;                                                // constant input carrying the layer-1 bias
+    rs_bcast_x16(xo, xs);
+    float v;
+    { float vv[1]; CRT.forward(xs, vv); v = vv[0]; }
+
+    RsOut O;
+    O.obs_row = tile + lane * RS_OBS_DIM;
+    O.reward = lds_rew + lane - (size_t)n;
+    O.team = nullptr;
+    O.done = lds_done + lane - (size_t)n;
+    O.oob = lds_oob + lane - (size_t)n;
+    O.oobc = nullptr; O.blocked = nullptr; O.collision = nullptr;
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * N + n;
+        float lg[8];
+        ACT.forward(xs, lg);
+        int a = 0;
+        float logp = 0.0f;
+        if (own) {
+            float mx = lg[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) mx = fmaxf(mx, lg[q]);
+            float se = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) se += __expf(lg[q] - mx);
+            const float lse = __logf(se);
+            const uint32_t episode = P.episode[n] - 1u, tenv = P.tstep[n];
+            u32x4 ph = philox4x32_10(0u, tenv, episode, RS_STREAM_ACT, k0, k1);
+            const float u = (float)(ph.x >> 8) * (1.0f / 16777216.0f);
+            float cdf = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float lpq = (lg[q] - mx) - lse;
+                cdf += __expf(lpq);
+                if (q < 7) a += (cdf <= u) ? 1 : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) logp = (a == q) ? ((lg[q] - mx) - lse) : logp;
+#pragma unroll
+            for (int k = 0; k < RS_OBS_DIM; ++k) tile[lane * RS_OBS_DIM + k] = xo[k];
+        }
+        __syncthreads();
+        {
+            float* dst = R.obs + ((size_t)t * N + (size_t)blockIdx.x * 16) * RS_OBS_DIM;
+            for (int i = lane; i < 16 * RS_OBS_DIM; i += RS_WAVE) dst[i] = tile[i];
+        }
+        __syncthreads();
+        bool cut = false;
+        float vb_own_dummy = 0.0f;
+        (void)vb_own_dummy;
+        bool over = false, boot = false, ended = t == T - 1;
+        if (own) {
+            R.act[row] = (int64_t)a;
+            R.logp[row] = logp;
+            R.val[row] = v;
+            R.source_tar[row * 2 + 0] = (float)P.src_x[n];
+            R.source_tar[row * 2 + 1] = (float)P.src_y[n];
+            rs_env_step_lane<HAS_OBS>(P, g, n, [&](int) -> int { return a; }, O);
+            const float r = lds_rew[lane];
+            const bool terminal = lds_done[lane] != 0;
+            oob_count += lds_oob[lane];
+            R.rew[row] = r;
+            ep_ret += r;
+            steps += 1;
+            done_count += terminal ? 1 : 0;
+            const bool timeout = steps == L;
+            over = terminal || timeout;
+            cut = over || ended;
+            boot = timeout || ended;
+#pragma unroll
+            for (int k = 0; k < RS_OBS_DIM; ++k) oraw[k] = tile[lane * RS_OBS_DIM + k];
+            W.update((double)oraw[0]);
+#pragma unroll
+            for (int k = 1; k < RS_OBS_DIM; ++k) xo[k] = oraw[k];
+            xo[0] = W.standardize(oraw[0]);
+        }
+        rs_bcast_x16(xo, xs);
+        float vb;
+        { float vv[1]; CRT.forward(xs, vv); vb = vv[0]; }
+        if (own) {
+            R.cut[row] = cut ? 1 : 0;
+            R.last_val[row] = (cut && boot) ? vb : 0.0f;
+            if (over) { ep_ret_sum += (double)ep_ret; ep_len_sum += (double)steps; ep_count += 1; }
+            if (cut) {
+                if (ended) P.epoch_end[n] = 1;
+                W.reset();
+                rs_env_reset_lane<HAS_OBS>(P, g, n, lds_geo, lds_adj, lds_d, tile + lane * RS_OBS_DIM, O);
+#pragma unroll
+                for (int k = 0; k < RS_OBS_DIM; ++k) oraw[k] = tile[lane * RS_OBS_DIM + k];
+                W.update((double)oraw[0]);
+#pragma unroll
+                for (int k = 1; k < RS_OBS_DIM; ++k) xo[k] = oraw[k];
+                xo[0] = W.standardize(oraw[0]);
+                steps = 0;
+                ep_ret = 0.0f;
+            }
+        }
+        v = vb;
+        if (__ballot(cut) != 0ull) {
+            rs_bcast_x16(xo, xs);
+            float vv[1];
+            CRT.forward(xs, vv);
+            v = cut ? vv[0] : vb;
+        }
+    }
+    if (own) {
+#pragma unroll
+        for (int k = 0; k < RS_OBS_DIM; ++k) R.cur_obs[(size_t)n * RS_OBS_DIM + k] = oraw[k];
+        R.w_count[n] = W.count; R.w_mean[n] = W.mean; R.w_sq[n] = W.sq; R.w_std[n] = W.std;
+        R.steps_in_ep[n] = steps;
+        R.ep_ret[n] = ep_ret;
+        R.done_count[n] = done_count; R.oob_count[n] = oob_count; R.ep_count[n] = ep_count;
+        R.ep_ret_sum[n] = ep_ret_sum; R.ep_len_sum[n] = ep_len_sum;
+    }
+}

@@ -472,7 +472,7 @@ class FusedCollector:
 
     def __init__(self, env: RadSearchVec, agents: Dict[int, VecAgentPPO], steps_per_epoch: int, steps_per_episode: int,
                  global_critic_flag: bool = False, standardize: bool = True):
-        assert env.number_agents == 1 and len(agents) == 1 and env.num_envs % 64 == 0 and standardize
+        assert env.number_agents == 1 and len(agents) == 1 and env.num_envs % 16 == 0 and standardize
         assert not global_critic_flag
         self.env, self.agents = env, agents
         self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, 1

@@ -120,7 +120,7 @@ class train_PPO:
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}
         for ag in self.agents.values():
             ag.sync_params()                                                   # train.py:248-256
-        fusable = (self.number_of_agents == 1 and self.vec.num_envs % 64 == 0 and self.vec.cfg.geom_group_size == 1
+        fusable = (self.number_of_agents == 1 and self.vec.num_envs % 16 == 0 and self.vec.cfg.geom_group_size == 1
                    and not self.global_critic_flag)
         cls = FusedCollector if fusable else Collector      # one launch per epoch (rs_rollout) when the config allows
         self.collector = cls(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
