@@ -190,3 +190,32 @@ def test_dict_api_adapter_matches_oracle():
             o, r, d, i = env.reset()
             ro, rr, rd, ri = ref.reset()
             assert np.array_equal(o[0].astype(np.float32), np.asarray(ro[0]).astype(np.float32))
+
+
+def test_single_env_and_max_agents():
+    """Edge sizes: one env (a 1-lane wave) and the maximum agent count (RS_MAX_AGENTS = 8) with collisions galore."""
+    _run(N=1, A=1, obst=0, enforce=True, steps=30, seed=11)
+    _run(N=3, A=8, obst=2, enforce=True, steps=24, ep_len=8, seed=12)
+
+
+def test_full_size_properties_no_oracle():
+    """BASELINE sizes (4096 envs and 2^18 envs) through size-independent properties: determinism (same seed -> same
+    bits), independence from the launch shape (a 4096-env handle equals the first 4096 envs of a 2^18-env handle),
+    integer-valued measurements, bounded coordinates and rewards on the 2-decimal lattice."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    big = RadSearchVec(1 << 18, enforce_grid_boundaries=True, seed=SEED)
+    a = RadSearchVec(4096, enforce_grid_boundaries=True, seed=SEED)
+    b = RadSearchVec(4096, enforce_grid_boundaries=True, seed=SEED)
+    big.reset(); a.reset(); b.reset()
+    g = torch.Generator().manual_seed(0)
+    for t in range(20):
+        acts = torch.randint(0, 9, (1 << 18, 1), generator=g).to(torch.int8).cuda()
+        ob, rb, _, db, _ = big.step(acts)
+        oa, ra, _, da, _ = a.step(acts[:4096].contiguous())
+        o2, r2, _, d2, _ = b.step(acts[:4096].contiguous())
+        assert torch.equal(oa, o2) and torch.equal(ra, r2) and torch.equal(da, d2)
+        assert torch.equal(ob[:4096], oa) and torch.equal(rb[:4096], ra) and torch.equal(db[:4096], da)
+        assert torch.equal(ob[..., 0], ob[..., 0].round()) and (ob[..., 0] >= 0).all()
+        assert (ob[..., 1:3] >= 0).all() and (ob[..., 1:3] < 2700 / 2200).all()
+        assert torch.allclose(rb * 100, (rb * 100).round(), atol=1e-4) and (rb <= 0.1 + 1e-6).all()
+    assert big.error_flags() == 0
