@@ -277,8 +277,10 @@ __device__ __forceinline__ bool rs_seg_rect_close(int px, int py, int qx, int qy
         int cx = (c >= 2) ? x1 : x0, cy = (c == 1 || c == 2) ? y1 : y0;
         int64_t dot = (int64_t)(cx - px) * dx + (int64_t)(cy - py) * dy;
         if (dot >= 0 && dot <= len2) {
+            // distance^2 = cr^2 / len2 < 1e-6.  len2 <= 1.5e7 on this lattice, so only |cr| <= 3 can qualify;
+            // testing that first also keeps cr^2 * 1e6 far away from int64 overflow (|cr| reaches 4e6).
             int64_t cr = (int64_t)(cx - px) * dy - (int64_t)(cy - py) * dx;
-            if (cr * cr * 1000000ll < len2) return true;
+            if (cr > -4 && cr < 4 && cr * cr * 1000000ll < len2) return true;
         }
     }
     return false;

@@ -219,3 +219,27 @@ def test_full_size_properties_no_oracle():
         assert (ob[..., 1:3] >= 0).all() and (ob[..., 1:3] < 2700 / 2200).all()
         assert torch.allclose(rb * 100, (rb * 100).round(), atol=1e-4) and (rb <= 0.1 + 1e-6).all()
     assert big.error_flags() == 0
+
+
+def test_line_of_sight_threshold_no_int64_overflow():
+    """is_intersect's exact 'distance < 1e-3' test (cr^2 * 1e6 < len2) with a corner 1800 cm off a 2827 cm line
+    of sight: cr = 3.6e6, cr^2 * 1e6 = 1.3e19 exceeds int64.  The state is written directly (rs_state_field) so
+    the geometry is exactly the adversarial one; an idle step must see the source (not blocked)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from oracle.radsearch_oracle import seg_rect_boundary_lt_1e3
+    vec = RadSearchVec(64, obstruction_count=1, enforce_grid_boundaries=True, seed=SEED)
+    vec.reset()
+    rect = (1900, 300, 2100, 500)
+    assert not seg_rect_boundary_lt_1e3(200, 200, 2199, 2199, rect)          # oracle: far from blocked
+    r = vec.state("rect"); r[0:4, :] = torch.tensor(rect, dtype=torch.int32, device="cuda").view(4, 1)
+    vec.state("num_obs")[:] = 1
+    vec.state("src_x")[:] = 2199; vec.state("src_y")[:] = 2199
+    vec.state("x")[:] = 200; vec.state("y")[:] = 200
+    d = float(np.sqrt(2.0) * 1999)
+    vec.state("sp")[:] = d; vec.state("prev")[:] = d
+    vec.state("dsrc")[:] = 1e9
+    obs, rew, _, _, _ = vec.step(torch.full((64, 1), 8, dtype=torch.int8, device="cuda"))
+    flags = vec.state("aflags").cpu().numpy()
+    assert (flags & 2).sum() == 0, "line of sight wrongly reported blocked (int64 overflow in the threshold test)"
+    inten = vec.state("intensity").cpu().numpy()[0]
+    assert (obs[:, 0, 0].cpu().numpy() > 0.5 * inten / d).all()
