@@ -209,7 +209,8 @@ struct RsGeo {
     }
 };
 
-__device__ __forceinline__ bool rs_frac_lt(int n1, int d1, int n2, int d2) { return (int64_t)n1 * d2 < (int64_t)n2 * d1; }
+// all lattice quantities fit int32: |coordinate| <= 16000 (rs_create), so |product| <= 1.03e9 and sums of two < 2^31
+__device__ __forceinline__ bool rs_frac_lt(int n1, int d1, int n2, int d2) { return n1 * d2 < n2 * d1; }
 
 // closed segment p-q meets the OPEN interior of [x0,x1]x[y0,y1]?  (exact)
 __device__ __forceinline__ bool rs_seg_hits_open_rect(int px, int py, int qx, int qy, int x0, int y0, int x1, int y1) {
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool rs_seg_hits_open_rect(int px, int py, int qx, in
 }
 
 __device__ __forceinline__ int rs_orient(int ax, int ay, int bx, int by, int cx, int cy) {
-    int64_t v = (int64_t)(bx - ax) * (cy - ay) - (int64_t)(by - ay) * (cx - ax);
+    const int v = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
     return (v > 0) - (v < 0);
 }
 __device__ __forceinline__ bool rs_on_seg(int ax, int ay, int bx, int by, int cx, int cy) {
@@ -270,17 +271,17 @@ __device__ __forceinline__ bool rs_seg_rect_close(int px, int py, int qx, int qy
         if (rs_segs_intersect(px, py, qx, qy, ax, ay, bx, by)) return true;
     }
     int dx = qx - px, dy = qy - py;
-    int64_t len2 = (int64_t)dx * dx + (int64_t)dy * dy;
+    const int len2 = dx * dx + dy * dy;
     if (len2 == 0) return false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         int cx = (c >= 2) ? x1 : x0, cy = (c == 1 || c == 2) ? y1 : y0;
-        int64_t dot = (int64_t)(cx - px) * dx + (int64_t)(cy - py) * dy;
+        const int dot = (cx - px) * dx + (cy - py) * dy;
         if (dot >= 0 && dot <= len2) {
             // distance^2 = cr^2 / len2 < 1e-6.  len2 <= 1.5e7 on this lattice, so only |cr| <= 3 can qualify;
             // testing that first also keeps cr^2 * 1e6 far away from int64 overflow (|cr| reaches 4e6).
-            int64_t cr = (int64_t)(cx - px) * dy - (int64_t)(cy - py) * dx;
-            if (cr > -4 && cr < 4 && cr * cr * 1000000ll < len2) return true;
+            const int cr = (cx - px) * dy - (cy - py) * dx;
+            if (cr > -4 && cr < 4 && cr * cr * 1000000 < len2) return true;
         }
     }
     return false;
@@ -597,6 +598,8 @@ __device__ __forceinline__ void rs_load_geo(const RsParams& P, int n, bool activ
         for (int w = 0; w < 4 * no; ++w) lds_geo[w * RS_WAVE + lane] = P.rect[(size_t)w * P.G + gi];
         g.r = lds_geo; g.stride = RS_WAVE; g.off = lane; g.n = no;
     }
+    // a fixed obstruction_count is wave-uniform (a kernel argument): loops over obstacles become scalar loops
+    if (P.obstruction_count > 0 && active) g.n = P.obstruction_count;
 }
 
 __device__ __forceinline__ void rs_copy_out(const RsParams& P, float* obs, const float* tile, const int* flags, int wave_env0) {

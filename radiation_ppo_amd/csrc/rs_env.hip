@@ -149,7 +149,7 @@ static bool cfg_ok(const rs_config* c) {
     if (c->obstruction_count < -1 || c->obstruction_count > RS_MAX_OBS) return false;
     if (c->geom_group_size < 1) return false;
     if (c->bbox[2] <= c->bbox[0] || c->bbox[3] <= c->bbox[1]) return false;
-    if (c->bbox[2] > 20000 || c->bbox[3] > 20000 || c->bbox[0] < -20000 || c->bbox[1] < -20000) return false;   // int32 predicates
+    if (c->bbox[2] > 16000 || c->bbox[3] > 16000 || c->bbox[0] < -16000 || c->bbox[1] < -16000) return false;   // int32 predicates
     if (c->observation_area[0] < 0 || c->observation_area[1] <= c->observation_area[0]) return false;
     return true;
 }
