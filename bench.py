@@ -157,6 +157,15 @@ def time_grad_pass(col, reps: int = 20):
     return e0.elapsed_time(e1) / reps, X.shape[0]
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,19 +259,23 @@ def main():
     }
 
     if rank == 0:
+        pmc = pmc_traffic() if N == ENVS_PER_GPU else None
         # dominant kernel of the PPO iteration: the fused loss+gradient pass (<= 40 launches per iteration), MFMA bound
         if args.collector == "fused":
             g_ms, g_m = time_grad_pass(col)
             tfl = PPO_GRAD_FLOPS_PER_SAMPLE * g_m / (g_ms * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad2_kernel<8> + rs_ppo_grad2_kernel<1> (+ rs_ppo_reduce_kernel)",
                                   "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
-                                  "traffic": None, "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
+                                  "traffic": pmc["grad_pass_bytes_per_launch"] if pmc else None,
+                                  "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if pmc else None,
+                                  "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
                                   "avg_launch_ms": g_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
         k1 = time_step_kernel(env)
         bytes_per_launch = K1_BYTES_PER_AGENT_STEP * N * 1
         achieved = bytes_per_launch / (k1["avg_ms"] * 1e-3) / 1e9
         result["roofline_env_step"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": pmc["env_step_4096_bytes_per_launch"] if pmc else None,
                               "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1["avg_ms"],
                               "median_launch_ms": k1["median_ms"], "back_to_back_ms": k1["train_ms"],
                               "env_only_steps_per_s": N / (k1["train_ms"] * 1e-3),
@@ -275,6 +288,7 @@ def main():
             ach = bpl / (kb["avg_ms"] * 1e-3) / 1e9
             result["roofline_env_step_large_n"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "envs": 1 << 20, "achieved": ach,
                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                          "traffic": pmc["env_step_1048576_bytes_per_launch"] if pmc else None, "bytes_per_launch": bpl,
                                           "avg_launch_ms": kb["avg_ms"], "env_only_steps_per_s": (1 << 20) / (kb["train_ms"] * 1e-3)}
             del big
         except Exception as e:  # noqa: BLE001

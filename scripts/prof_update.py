@@ -21,3 +21,13 @@ for _ in range(reps):
     f(X, act, adv, ret, lpo, w, 0.2, 0.1)
 torch.cuda.synchronize()
 print(f"rollout {t_roll*1e3:.2f} ms; grad pass {(time.perf_counter()-t0)/reps*1e3:.3f} ms (M={X.shape[0]})")
+# env-step kernel at the two sizes bench.py reports
+acts = torch.randint(0, 9, (N, 1), device="cuda").to(torch.int8)
+for _ in range(5):
+    env.step(acts)
+big = RadSearchVec(1 << 20, enforce_grid_boundaries=True, seed=289714752)
+big.reset()
+ab = torch.randint(0, 9, (1 << 20, 1), device="cuda").to(torch.int8)
+for _ in range(5):
+    big.step(ab)
+torch.cuda.synchronize()
