@@ -736,7 +736,7 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v2 = rs_grad_version() == 2;
-    const int waves = RS_GRAD_BLOCKS * (v2 ? 8 : 4);
+    const int waves = v2 ? RS_GRAD_BLOCKS : RS_GRAD_BLOCKS * 4;      // v2 reduces its 8 waves in LDS: one slab per workgroup
     float* pa = static_cast<float*>(workspace);
     float* pc = pa + (size_t)waves * rs_net_params(8);
     double* sa = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pc + (size_t)waves * rs_net_params(1)) + 255) & ~uintptr_t(255));

@@ -344,33 +344,19 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         rs_wave_sync();
     }
 
-    // ---- one partial slab per wave, parameter order {w1, b1, w2, b2, w3, b3}
-    float* outp = partial + (size_t)wave_g * rs_net_params(NOUT);
-    float* g_w1 = outp, *g_b1 = g_w1 + 64 * 11, *g_w2 = g_b1 + 64, *g_b2 = g_w2 + 64 * 64, *g_w3 = g_b2 + 64, *g_b3 = g_w3 + NOUT * 64;
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * it + rs_kappa(r, h);
-            g_w2[row * 64 + c] = acc2[it][0][r];
-            g_w2[row * 64 + 32 + c] = acc2[it][1][r];
-        }
-    g_b2[lane] = dbl[lane];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 16 * u + 4 * l4 + q;
-            if (l15 < RS_IN) g_w1[row * RS_IN + l15] = acc1[u][q];
-            if (l15 == RS_IN) g_b1[row] = acc1[u][q];
-            const int o = 4 * l4 + q;
-            if (o < NOUT) g_w3[o * 64 + 16 * u + l15] = acc3[u][q];
-        }
+    // ---- one partial slab per WORKGROUP, parameter order {w1, b1, w2, b2, w3, b3}: the eight waves add their
+    // accumulators into one LDS slab in wave order (fixed order -> reproducible), then the block streams it out.
+    __syncthreads();                                  // every wave is done with its staging tiles
+    float* red = w3tf + 2 * 4 * 64;                   // reuse the staging region: rs_net_params(NOUT) floats
+    double* sred = reinterpret_cast<double*>(red + ((rs_net_params(NOUT) + 1) & ~1));
+    float* g_w1 = red, *g_b1 = g_w1 + 64 * 11, *g_w2 = g_b1 + 64, *g_b2 = g_w2 + 64 * 64, *g_w3 = g_b2 + 64, *g_b3 = g_w3 + NOUT * 64;
+    const float db2v = dbl[lane];                     // (dbl lives in the region being overwritten: read it first)
+    float db3r[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         float v = db3[o];
         v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-        if (lane == 0) g_b3[o] = v;
+        db3r[o] = v;
     }
     double sv[5];
     if (NOUT == 8) { sv[0] = st0; sv[1] = st1; sv[2] = st2; sv[3] = 0.0; sv[4] = st3; }
@@ -379,6 +365,41 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
     for (int q = 0; q < 5; ++q) {
         double v = sv[q];
         v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-        if (lane == 0) stat_partial[(size_t)wave_g * 5 + q] = v;
+        sv[q] = v;
     }
+    __syncthreads();                                  // all dbl reads done before the slab is written
+    for (int wv = 0; wv < 8; ++wv) {
+        if (wid == wv) {
+            const bool first = wv == 0;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * it + rs_kappa(r, h);
+                    g_w2[row * 64 + c] = (first ? 0.0f : g_w2[row * 64 + c]) + acc2[it][0][r];
+                    g_w2[row * 64 + 32 + c] = (first ? 0.0f : g_w2[row * 64 + 32 + c]) + acc2[it][1][r];
+                }
+            g_b2[lane] = (first ? 0.0f : g_b2[lane]) + db2v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 16 * u + 4 * l4 + q;
+                    if (l15 < RS_IN) g_w1[row * RS_IN + l15] = (first ? 0.0f : g_w1[row * RS_IN + l15]) + acc1[u][q];
+                    if (l15 == RS_IN) g_b1[row] = (first ? 0.0f : g_b1[row]) + acc1[u][q];
+                    const int o = 4 * l4 + q;
+                    if (o < NOUT) g_w3[o * 64 + 16 * u + l15] = (first ? 0.0f : g_w3[o * 64 + 16 * u + l15]) + acc3[u][q];
+                }
+            if (lane == 0) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) g_b3[o] = (first ? 0.0f : g_b3[o]) + db3r[o];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) sred[q] = (first ? 0.0 : sred[q]) + sv[q];
+            }
+        }
+        __syncthreads();
+    }
+    float* outp = partial + (size_t)blockIdx.x * rs_net_params(NOUT);
+    for (int i = threadIdx.x; i < rs_net_params(NOUT); i += blockDim.x) outp[i] = red[i];
+    if (threadIdx.x < 5) stat_partial[(size_t)blockIdx.x * 5 + threadIdx.x] = sred[threadIdx.x];
 }
