@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "librs_hip.so")
+LIB_PATH = os.environ.get("RS_LIB_PATH") or os.path.join(_PKG, "lib", "librs_hip.so")   # override: A/B builds
 
 RS_OBS_DIM = 11
 RS_MAX_AGENTS = 8

@@ -309,12 +309,10 @@ __device__ __forceinline__ double rs_shortest_path(const RsGeo& g, const double*
     double best = INFINITY;
     for (int v = 0; v < 4 * g.n; ++v) {
         double d = dsrc[(size_t)v * N + n];
-        if (d < INFINITY) {
+        if (d < best) {                       // exact prune: d + |v-p| >= d, a vertex at d >= best cannot improve
             int vx, vy; g.vertex(v, vx, vy);
-            if (rs_visible(g, vx, vy, px, py)) {
-                double c = d + rs_dist_i(vx, vy, px, py);
-                if (c < best) best = c;
-            }
+            const double c = d + rs_dist_i(vx, vy, px, py);
+            if (c < best && rs_visible(g, vx, vy, px, py)) best = c;     // visibility only for improving candidates
         }
     }
     return best;
@@ -358,6 +356,9 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
             if (!(px + 100 < x0 || px - 100 > x1 || py + 100 < y0 || py - 100 > y1)) near |= 1u << o;
         }
     }
+#if defined(RS_ABL) && RS_ABL == 1
+    near = 0;
+#endif
     if (HAS_OBS && near != 0) {
         uint64_t cnt = 0;      // obs_idx_ls packed 8 bits per obstacle
         int ones = 0;
@@ -367,9 +368,13 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
             int qx = px + sx_, qy = py + sy_;
             int inter = 0;
             double dmax = 0.0;
-            for (int o = 0; o < g.n; ++o) {
-                if (!(near >> o & 1u)) continue;
+            // visit only the obstacles a probe can reach, in ascending index order (the reference's order);
+            // the per-lane trip count is popcount(near) (typically 0-1) instead of the obstacle count
+            for (uint32_t rem = near; rem != 0; rem &= rem - 1) {
+                const int o = __ffs((int)rem) - 1;
                 int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+                // exact prune: the probe's bounding box does not touch the rectangle -> no edge can be hit
+                if (max(px, qx) < x0 || min(px, qx) > x1 || max(py, qy) < y0 || min(py, qy) > y1) continue;
                 double m = 0.0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -522,8 +527,16 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
         // ---- distances, line of sight, measurement, reward :486-567
         double euc = rs_dist_i(x, y, sx, sy);               // == the stale euc_dist when stalled (position unchanged)
         double reward;
+#if defined(RS_ABL) && RS_ABL == 3
+        if (moved) sp = euc;
+#else
         if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, sx, sy, x, y) : euc;
+#endif
+#if defined(RS_ABL) && RS_ABL == 2
+        bool inter = false;
+#else
         bool inter = (HAS_OBS && g.n > 0) ? rs_is_intersect(g, px, py, sx, sy, euc, sp) : false;
+#endif
         fl = (uint8_t)((fl & ~RS_AF_INTERSECT) | (inter ? RS_AF_INTERSECT : 0));
         double lam;
         if (inter) lam = (double)bkg;
