@@ -53,7 +53,8 @@ enum {
     RS_ENVERR_ZERO_DIST = 1,   /* detector on the source: intensity / 0 (rad_search_env.py:501)            */
     RS_ENVERR_IDLE_STALL = 2,  /* idle action stalled without collision (ValueError, :544-547, :562-565)  */
     RS_ENVERR_CORRECT_CAP = 4, /* correct_coords loop (:1278) hit the iteration cap                       */
-    RS_ENVERR_BAD_ACTION = 8   /* action outside 0..8 / -1 (assert, :616-627)                             */
+    RS_ENVERR_BAD_ACTION = 8,  /* action outside 0..8 / -1 (assert, :616-627)                             */
+    RS_ENVERR_NO_PATH = 16     /* no obstacle-free path detector -> source (cannot happen in a valid world) */
 };
 
 typedef struct rs_config {

@@ -62,6 +62,7 @@ DIR_COEFF = ((-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1
 
 ERR_ZERO_DIST = 1       # detector on the source: reference divides by zero (:501) and raises
 ERR_IDLE_STALL = 2      # reference raises ValueError (:544-547, :562-565)
+ERR_NO_PATH = 16        # shortest path is infinite (cannot happen in a world that passed is_valid)
 ERR_CORRECT_CAP = 4     # correct_coords (:1278) did not terminate within the cap
 
 
@@ -191,19 +192,37 @@ class PhiloxGeomDraws:
         return lo + ((x * (hi - lo)) >> 64)
 
 
+def layout_is_valid(rects):
+    """world.is_valid(EPSILON) (:788) for lattice rectangles that passed create_obs.
+
+    VisiLibity1 (un-vendored dependency, Environment::is_valid in visilibity.cpp) requires: every polygon simple;
+    no two boundaries within epsilon; every hole vertex inside the outer boundary and in NO other hole; outer
+    boundary counter-clockwise, holes clockwise.  create_obs emits clockwise rectangles of extent >= 200 strictly
+    inside the walls with pairwise disjoint boundaries, so the one clause that can fail is "a vertex of hole i is
+    in hole k": one rectangle nested inside another (boundaries disjoint => one vertex inside means all four)."""
+    for i, r in enumerate(rects):
+        for k, q in enumerate(rects):
+            if i != k and q[0] <= r[0] <= q[2] and q[1] <= r[1] <= q[3]:
+                return False
+    return True
+
+
 def sample_layout(draws, obstruction_count, sa_x0=200, sa_y0=200, sa_x1=2200, sa_y1=2200, oa=(200, 500)):
-    """create_obs (:948-1011) + the num_obs draw (:745-750) as a free function (shared layouts)."""
-    num = draws.integers(1, 6) if obstruction_count == -1 else obstruction_count
-    rects = []
-    while len(rects) < num:
-        sx = draws.integers(sa_x0, int(sa_x1 * 0.9))
-        sy = draws.integers(sa_y0, int(sa_y1 * 0.9))
-        ex = draws.integers(oa[0], oa[1])
-        ey = draws.integers(oa[0], oa[1])
-        r = (sx, sy, sx + ex, sy + ey)
-        if not any(RadSearchOracle._rect_boundaries_touch(q, r) for q in rects):
-            rects.append(r)
-    return rects
+    """create_obs (:948-1011) + the num_obs draw (:745-750) as a free function (shared layouts), redrawn until
+    world.is_valid (:788) holds."""
+    while True:
+        num = draws.integers(1, 6) if obstruction_count == -1 else obstruction_count
+        rects = []
+        while len(rects) < num:
+            sx = draws.integers(sa_x0, int(sa_x1 * 0.9))
+            sy = draws.integers(sa_y0, int(sa_y1 * 0.9))
+            ex = draws.integers(oa[0], oa[1])
+            ey = draws.integers(oa[0], oa[1])
+            r = (sx, sy, sx + ex, sy + ey)
+            if not any(RadSearchOracle._rect_boundaries_touch(q, r) for q in rects):
+                rects.append(r)
+        if layout_is_valid(rects):
+            return rects
 
 
 class ReplayDraws:
@@ -481,6 +500,7 @@ class RadSearchOracle:
         self.episode = 0
         self.t = 0
         self.err = 0
+        self.invalid_layouts = 0     # layouts rejected by world.is_valid (test bookkeeping)
         self.last_lam = [0.0] * number_agents
         self._ret = self.reset()
 
@@ -568,6 +588,8 @@ class RadSearchOracle:
                     self.err |= ERR_IDLE_STALL
                 reward = -0.5 * agent.sp_dist / self.max_dist
         self.last_lam[agent.id] = lam
+        if not agent.sp_dist < math.inf:
+            self.err |= ERR_NO_PATH
         # observation (:577-593); coord_noise is not supported (always 0.0)
         s = 1 / float(self.sa_y1)
         ox = (agent.det[0] + 0.0) * s
@@ -582,13 +604,14 @@ class RadSearchOracle:
         return state, round2(reward), self.done, info
 
     # ------------------------------------------------------------------ reset (:730-797)
-    def reset(self):
+    def reset(self, _nested=False):
         for agent in self.agents.values():
             agent.reset()
         self.done = False
         self.iter_count = 0
-        self.rng.begin_reset(self.episode)
-        self.t = 0
+        if not _nested:          # a nested retry (:788-791) continues the same draw sequence and step counter
+            self.rng.begin_reset(self.episode)
+            self.t = 0
         if self.epoch_end and self.layout_fn is not None:
             self.rects = list(self.layout_fn())
             self.num_obs = len(self.rects)
@@ -610,10 +633,16 @@ class RadSearchOracle:
             agent.prev_det_dist = shortest_path_len(self.src[0], self.src[1], det[0], det[1], self.rects, self.dsrc)
         self.intensity = self.rng.integers(1000000, 10000000)     # :778 (1e6, 10e6)
         self.bkg_intensity = self.rng.integers(10, 51)            # :779
-        # world.is_valid (:788) is always true for lattice rectangles that passed create_obs
+        # :788-791 "Environment is not valid, retrying!": a full nested reset with a new layout, after which the
+        # outer call still runs its own step(None) -- k rejected layouts cost k extra idle measurements.
+        if self.layout_fn is None and not layout_is_valid(self.rects):
+            self.epoch_end = True
+            self.invalid_layouts += 1
+            self.reset(_nested=True)
         ret = self.step(None)
         self.iter_count = 0
-        self.episode += 1
+        if not _nested:
+            self.episode += 1
         return ret
 
     # ------------------------------------------------------------------ take_action (:876-946)

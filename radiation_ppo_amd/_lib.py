@@ -19,6 +19,7 @@ ENVERR_ZERO_DIST = 1
 ENVERR_IDLE_STALL = 2
 ENVERR_CORRECT_CAP = 4
 ENVERR_BAD_ACTION = 8
+ENVERR_NO_PATH = 16
 
 
 class RsConfig(C.Structure):

@@ -27,6 +27,7 @@
 #define RS_ENVERR_IDLE_STALL 2u
 #define RS_ENVERR_CORRECT_CAP 4u
 #define RS_ENVERR_BAD_ACTION 8u
+#define RS_ENVERR_NO_PATH 16u
 
 #define RS_AF_BLOCKED 1
 #define RS_AF_INTERSECT 2
@@ -532,6 +533,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
 #else
         if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, sx, sy, x, y) : euc;
 #endif
+        if (HAS_OBS && !(sp < INFINITY)) err |= RS_ENVERR_NO_PATH;
 #if defined(RS_ABL) && RS_ABL == 2
         bool inter = false;
 #else
@@ -664,6 +666,20 @@ __device__ __forceinline__ int rs_create_obs(const RsParams& P, RsDrawSeq& seq, 
     return num;
 }
 
+// world.is_valid(EPSILON) (:788) for a layout that passed create_obs: the one VisiLibity clause that can fail is
+// "a vertex of hole i is in hole k", i.e. a rectangle nested inside another (boundaries are already disjoint).
+__device__ __forceinline__ bool rs_layout_valid(const int* lds_geo, int stride, int off, int num) {
+    for (int i = 0; i < num; ++i) {
+        const int vx = lds_geo[(i * 4 + 0) * stride + off], vy = lds_geo[(i * 4 + 1) * stride + off];
+        for (int k = 0; k < num; ++k) {
+            if (k == i) continue;
+            const int x0 = lds_geo[(k * 4 + 0) * stride + off], y0 = lds_geo[(k * 4 + 1) * stride + off];
+            const int x1 = lds_geo[(k * 4 + 2) * stride + off], y1 = lds_geo[(k * 4 + 3) * stride + off];
+            if (x0 <= vx && vx <= x1 && y0 <= vy && vy <= y1) return false;
+        }
+    }
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------
 // RadSearch.reset for env n (one lane): rad_search_env.py:730-797 with create_obs (per-env layouts),
@@ -677,22 +693,28 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     const uint32_t episode = P.episode[n];
     RsDrawSeq seq{P.seed, P.env_id_base + (uint32_t)n, episode, RS_STREAM_RESET, 0u};
     // ---- per-env obstacle layout (geom_group_size == 1): resample when epoch_end is set (:744-762)
+    bool resample = false;
     if (HAS_OBS && P.group == 1) {
         g.r = lds_geo; g.stride = RS_WAVE; g.off = lane;
-        if (P.epoch_end[n]) {
-            int num = rs_create_obs(P, seq, lds_geo, RS_WAVE, lane);
-            P.num_obs[n] = num;
-            for (int w = 0; w < 4 * num; ++w) P.rect[(size_t)w * P.G + n] = lds_geo[w * RS_WAVE + lane];
-            g.n = num;
-        } else {
+        resample = P.epoch_end[n] != 0;
+        if (!resample) {
             g.n = P.num_obs[n];
             for (int w = 0; w < 4 * g.n; ++w) lds_geo[w * RS_WAVE + lane] = P.rect[(size_t)w * P.G + n];
         }
     }
     P.epoch_end[n] = 0;
+    // "Environment is not valid, retrying!" (:788-791): a layout that fails world.is_valid costs a complete nested
+    // reset -- its source/detector/intensity draws are consumed, then everything is drawn again -- and one more
+    // step(None) per rejected layout after the loop.
+    int extra_idle = 0;
+    int srx, sry, dtx, dty, intensity, bkg;
+    for (;;) {
+    if (resample) {
+        g.n = rs_create_obs(P, seq, lds_geo, RS_WAVE, lane);
+    }
     // ---- sample_source_loc_pos (:1013-1131); rand_point uses the x-range for both axes (:1033)
-    int srx = seq.integers(P.sa_x0, P.sa_x1), sry = seq.integers(P.sa_x0, P.sa_x1);
-    int dtx = seq.integers(P.sa_x0, P.sa_x1), dty = seq.integers(P.sa_x0, P.sa_x1);
+    srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1);
+    dtx = seq.integers(P.sa_x0, P.sa_x1); dty = seq.integers(P.sa_x0, P.sa_x1);
     for (;;) {
         bool inside = false;
         for (int o = 0; o < g.n && !inside; ++o) {
@@ -714,6 +736,15 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
         if (g.n == 0 || (num_retry > 20 && !resamp)) break;
         else if (resamp || !inter) { srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1); num_retry += 1; }
         else break;
+    }
+    intensity = seq.integers(1000000, 10000000);    // :778
+    bkg = seq.integers(10, 51);                     // :779
+    if (!resample || rs_layout_valid(lds_geo, RS_WAVE, lane, g.n)) break;
+    extra_idle += 1;
+    }
+    if (resample) {
+        P.num_obs[n] = g.n;
+        for (int w = 0; w < 4 * g.n; ++w) P.rect[(size_t)w * P.G + n] = lds_geo[w * RS_WAVE + lane];
     }
     // ---- geodesic distances source -> rectangle vertices (visibility graph relaxation)
     const int V = HAS_OBS ? 4 * g.n : 0;
@@ -746,8 +777,6 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     }
     for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + lane];
     double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
-    int intensity = seq.integers(1000000, 10000000);    // :778
-    int bkg = seq.integers(10, 51);                     // :779
     // ---- state write (Agent.reset :292-301, reset :736-742, :771-776)
     P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = intensity; P.bkg[n] = bkg;
     P.done[n] = 0; P.iter_count[n] = 0; P.tstep[n] = 0;
@@ -759,6 +788,8 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     RsOut o = O;
     o.obs_row = obs_row;
     P.episode[n] = episode + 1;       // draws of this episode are keyed by `episode`
-    rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
-    P.iter_count[n] = 0;
+    for (int k = 0; k <= extra_idle; ++k) {
+        rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
+        P.iter_count[n] = 0;
+    }
 }

@@ -55,7 +55,9 @@ __global__ void __launch_bounds__(64) rs_geom_kernel(RsParams P, const uint8_t* 
     const int n0 = gi * P.group;                       // the group's first env decides
     if (!P.epoch_end[n0] || (mask && !mask[n0])) return;
     RsDrawSeq seq{P.seed, P.env_id_base + (uint32_t)n0, P.geom_epoch[gi], RS_STREAM_GEOM, 0u};
-    int num = rs_create_obs(P, seq, lds_geo, RS_WAVE, lane);
+    int num;
+    do num = rs_create_obs(P, seq, lds_geo, RS_WAVE, lane);      // redrawn until world.is_valid (:788) holds
+    while (!rs_layout_valid(lds_geo, RS_WAVE, lane, num));
     P.num_obs[gi] = num;
     for (int w = 0; w < 4 * num; ++w) P.rect[(size_t)w * P.G + gi] = lds_geo[w * RS_WAVE + lane];
     P.geom_epoch[gi] += 1;

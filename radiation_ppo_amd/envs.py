@@ -261,6 +261,8 @@ class RadSearch:
             raise ValueError("Agent should not return false if the tentative step is an idle step")
         if flags & _lib.ENVERR_ZERO_DIST:
             raise ValueError("lam value too large")     # numpy's poisson(inf) error in the reference
+        if flags & _lib.ENVERR_NO_PATH:
+            raise RuntimeError("no obstacle-free path from the detector to the source")
         observation = {i: obs_c[i] for i in range(A)}
         reward = {"team_reward": float(np.float32(team[0].item())),
                   "individual_reward": {i: float(np.float32(rew_c[i])) for i in range(A)}}

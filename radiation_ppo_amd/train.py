@@ -144,6 +144,9 @@ class train_PPO:
             if self.world > 1:
                 dist.all_reduce(pack)
             done_c, oob_c, ret_s, len_s, ep_c = pack.tolist()
+            flags = self.vec.error_flags()      # the reference raises on these states (rad_search_env.py:544-565)
+            if flags:
+                raise RuntimeError(f"RadSearch env error flags 0x{flags:x} (see RS_ENVERR_* in include/radsearch.h)")
             dt = time.time() - t0
             for i in self.agents:
                 v = self.collector.buf.val[:, :, i]

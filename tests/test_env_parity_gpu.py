@@ -103,6 +103,7 @@ def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="refere
             t_in_ep[mask] = 0
     assert vec.error_flags() == 0
     assert all(e.err == 0 for e in refs)
+    return refs
 
 
 def test_obstacle_free_single_agent_enforced():
@@ -243,3 +244,13 @@ def test_line_of_sight_threshold_no_int64_overflow():
     assert (flags & 2).sum() == 0, "line of sight wrongly reported blocked (int64 overflow in the threshold test)"
     inten = vec.state("intensity").cpu().numpy()[0]
     assert (obs[:, 0, 0].cpu().numpy() > 0.5 * inten / d).all()
+
+
+@pytest.mark.parametrize("A,base,N", [(1, 190, 40), (2, 3815, 20)])
+def test_nested_layout_is_rejected_like_world_is_valid(A, base, N):
+    """Env ids 199, 215 / 3828, 3829 draw a rectangle nested inside another as their first layout:
+    world.is_valid fails (rad_search_env.py:788-791), the reset is redone with fresh draws and one more
+    step(None) runs.  Without the retry the detector can land on the inner boundary inside the outer
+    rectangle, where no path exists and the reward is -inf."""
+    refs = _run(N=N, A=A, obst=-1, enforce=True, steps=40, base=base)
+    assert sum(e.invalid_layouts for e in refs) >= 2

@@ -336,3 +336,30 @@ def test_device_side_update_loop_matches_torch_adam():
         assert abs(r1.kl_divergence - r2.kl_divergence) < 1e-5 and abs(r1.loss_policy - r2.loss_policy) < 1e-4
         for p1, p2 in zip(a1.agent.parameters(), a2.agent.parameters()):
             assert torch.allclose(p1, p2, rtol=1e-4, atol=2e-5), (p1 - p2).abs().max()
+
+
+def test_obstacle_training_stays_finite():
+    """Regression: 1-5 random obstacles per env (reference default obstruction_count=-1).  A layout with a
+    nested rectangle used to slip through reset and could yield an unreachable detector (reward -inf, NaN KL
+    from the 4th PPO iteration on); world.is_valid (rad_search_env.py:788-791) now rejects it at reset."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO
+    env = RadSearchVec(8192, obstruction_count=-1, enforce_grid_boundaries=True, seed=289714752)
+    agents = {0: VecAgentPPO(id=0, steps_per_epoch=240, steps_per_episode=120, alpha=0.1)}
+    col = FusedCollector(env, agents, 240, 120)
+    for _ in range(3):
+        col.collect()
+        for name in ("obs", "rew", "val", "adv", "ret"):
+            assert torch.isfinite(getattr(col.buf, name)).all(), name
+        r = col.update()[0]
+        assert np.isfinite(r.kl_divergence) and np.isfinite(r.loss_policy)
+    assert env.error_flags() == 0
+    num = env.state("num_obs")[0]
+    rect = env.state("rect").view(7, 4, -1)[:5]                       # [obstacle, (x0,y0,x1,y1), env]
+    live = torch.arange(5, device=num.device)[:, None] < num[None, :]
+    for i in range(5):
+        for k in range(5):
+            if i != k:
+                nested = ((rect[k, 0] <= rect[i, 0]) & (rect[i, 0] <= rect[k, 2]) & (rect[k, 1] <= rect[i, 1])
+                          & (rect[i, 1] <= rect[k, 3]) & live[i] & live[k])
+                assert not nested.any()
