@@ -186,7 +186,9 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
  * (algos/multiagent/ppo.py:1206-1225) in its batched form
  *     L = -( sum_i w_i min(r_i A_i, clip(r_i, 1-c, 1+c) A_i)  -  vf * sum_i w_i (V_i - R_i)^2  +  alpha * sum_i w_i H_i )
  * (w_i = 1 / (#ranks * #episodes of the sample's rank * length of its episode): the reference's mean over
- * ranks of the mean over episodes of per-episode means), its statistics, and dL/dtheta for every parameter of
+ * ranks of the mean over episodes of per-episode means; H_i enters as a DETACHED scalar exactly as in the
+ * reference, `ent = pi.entropy().detach().mean().item()` ppo.py:1216, so alpha moves the loss value but
+ * contributes no gradient), its statistics, and dL/dtheta for every parameter of
  * the actor and the critic: forward, loss, backward and the weight-gradient GEMMs (contraction over samples,
  * operands transposed through LDS) all on the matrix cores, gradients reduced deterministically.
  * Replaces loss_pi.backward() (ppo.py:1253-1254) for the FF_core networks.

@@ -349,10 +349,9 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
             const bool inside = ratio >= lo && ratio <= hi;
             const float dr = (inside || s1 < s2) ? adv : 0.0f;           // d min(r A, clip(r) A) / dr
             const float g_lp = -wi * dr * ratio;                          // d(-w surr)/d logp
-            const float g_h = -B.alpha * wi;                              // d(-alpha w H)/dH
+            // alpha * H is a detached scalar in the reference (ppo.py:1216 `.detach().mean().item()`): loss value only
 #pragma unroll
-            for (int j = 0; j < NOUT; ++j)
-                dz[j] = g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j]) + g_h * (-pj[j] * (lp[j] + ent));
+            for (int j = 0; j < NOUT; ++j) dz[j] = g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j]);
             st_kl += (double)(wi * (lpo - logp));
             st_ent += (double)(wi * ent);
             st_cf += (double)(wi * ((ratio > hi || ratio < lo) ? 1.0f : 0.0f));

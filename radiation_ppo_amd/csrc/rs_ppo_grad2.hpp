@@ -183,10 +183,10 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
             const bool inside = ratio >= lo && ratio <= hi;
             const float dr = (inside || s1 < s2) ? adv : 0.0f;
             const float g_lp = -wi * dr * ratio;
-            const float g_h = -B.alpha * wi;
+            // the entropy bonus is a detached scalar in the reference (`ent = pi.entropy().detach().mean().item()`,
+            // ppo.py:1216): alpha * H moves the loss VALUE only, no gradient flows through it
 #pragma unroll
-            for (int j = 0; j < NOUT; ++j)
-                dz[j] = g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j]) + g_h * (-pj[j] * (lp[j] + ent));
+            for (int j = 0; j < NOUT; ++j) dz[j] = g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j]);
             if (h == 0) {
                 st0 += (double)(wi * (lpo - logp));
                 st1 += (double)(wi * ent);

@@ -297,7 +297,8 @@ class VecAgentPPO:
             surr = torch.min(ratio * adv, clip_adv)
             val_loss = (w * (v - ret) ** 2).sum()
             ent_m = (w * ent).sum()
-            loss = -((w * surr).sum() - 0.01 * val_loss + self.alpha * ent_m)
+            # the entropy bonus is a detached scalar in the reference (`.detach().mean().item()`, ppo.py:1216)
+            loss = -((w * surr).sum() - 0.01 * val_loss + self.alpha * ent_m.detach())
             with torch.no_grad():
                 clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
                 stats = torch.stack([(w * (logp_old - logp)).sum(), ent_m.detach(), (w * clipped.float()).sum(),

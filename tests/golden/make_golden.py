@@ -428,11 +428,202 @@ def gen_round2():
     print("wrote round2.npz")
 
 
+def gen_train_trace():
+    """SURVEY 8c fixture (7), row T: the control flow of train_PPO.train (algos/multiagent/train.py:259-627) executed by
+    the reference's OWN method over the reference's OWN env.  The agents and loggers are recording stand-ins (the
+    reference's AgentPPO rejects 'ff' and its CNN wiring is mid-refactor), so what is pinned is exactly the
+    loop: call order, the terminal flag passed to store(), which steps bootstrap and with which value, when
+    env.epoch_end is raised, when env.reset()/reset_agent() run and what reaches the loggers."""
+    import json
+    import types
+    from gym_rad_search.envs.rad_search_env import RadSearch
+    from algos.multiagent import train as RT
+
+    out = {}
+    for name, A, global_critic, T, L, epochs, seed in (("a1_individual", 1, False, 50, 18, 3, 5),
+                                                        ("a2_team", 2, True, 44, 16, 3, 9)):
+        rec = RecordingGenerator(seed)
+        env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0, enforce_grid_boundaries=True)
+        ev = []
+        script = np.random.default_rng(77 + A)
+        counter = {"calls": 0, "episode": 0}
+
+        class EnvProxy:
+            def reset(self_):
+                ev.append(["env_reset"])
+                counter["episode"] += 1
+                return env.reset()
+
+            def step(self_, action=None):
+                ev.append(["env_step", {str(k): int(v) for k, v in action.items()}])
+                return env.step(action=action)
+
+            def __getattr__(self_, k):
+                return getattr(env, k)
+
+            def __setattr__(self_, k, v):
+                if k == "epoch_end":
+                    ev.append(["epoch_end_set", bool(v)])
+                setattr(env, k, v)
+
+        class Agent:
+            def __init__(self_, id):
+                self_.id = id
+
+            def step(self_, observations, hidden=None, message=None):
+                counter["calls"] += 1
+                val = 0.001 * counter["calls"]
+                # even episodes head for the source (terminal branch), odd ones wander
+                greedy = counter["episode"] % 2 == 0 and self_.id == 0      # a second greedy agent would only collide
+                act = _greedy_action(env, self_.id) if greedy else int(script.integers(0, 9))
+                ev.append(["agent_step", self_.id, {str(k): np.asarray(v, dtype=np.float64).tolist() for k, v in observations.items()},
+                           act, val])
+                return types.SimpleNamespace(action=act, state_value=val, action_logprob=-0.5 - val, hiddens=None), None
+
+            def store(self_, obs, rew, act, val, logp, src, terminal, heatmap_stacks, full_observation):
+                ev.append(["store", self_.id, np.asarray(obs, dtype=np.float64).tolist(), float(rew), int(act), float(val),
+                           float(logp), np.asarray(src, dtype=np.float64).tolist(), bool(terminal)])
+
+            def GAE_advantage_and_rewardsToGO(self_, last_state_value):
+                ev.append(["gae", self_.id, float(last_state_value)])
+
+            def store_episode_length(self_, episode_length):
+                ev.append(["ep_len", self_.id, int(episode_length)])
+
+            def reset_agent(self_):
+                ev.append(["reset_agent", self_.id])
+
+            def reduce_pfgru_training(self_):
+                ev.append(["reduce_pfgru", self_.id])
+
+            def save(self_, path=None):
+                ev.append(["save", self_.id])
+
+            def update_agent(self_, logger=None):
+                ev.append(["update", self_.id])
+                return types.SimpleNamespace(stop_iteration=1, loss_policy=0.0, loss_critic=0.0, loss_predictor=0.0,
+                                             kl_divergence=0.0, Entropy=0.0, ClipFrac=0.0, LocLoss=0.0, VarExplain=0.0)
+
+        class Logger:
+            output_dir = None
+
+            def __init__(self_, id):
+                self_.id = id
+
+            def store(self_, **kw):
+                for k, v in kw.items():
+                    if k in ("EpRet", "EpLen", "DoneCount", "OutOfBound"):
+                        ev.append(["log", self_.id, k, float(v)])
+
+            def log_tabular(self_, key, val=None, **kw):
+                if key == "TotalEnvInteracts":
+                    ev.append(["tabular", self_.id, key, float(val)])
+
+            def dump_tabular(self_):
+                ev.append(["dump", self_.id])
+
+            def log(self_, *a, **k):
+                pass
+
+        sim = object.__new__(RT.train_PPO)      # skip __post_init__ (builds the real agents / loggers)
+        sim.env = EnvProxy()
+        sim.logger_kwargs = dict(data_dir=".", env_name="x", exp_name="x", seed=0)
+        sim.ppo_kwargs = {}
+        sim.seed, sim.number_of_agents = 0, A
+        sim.actor_critic_architecture, sim.global_critic_flag = "cnn", global_critic
+        sim.steps_per_epoch, sim.steps_per_episode, sim.total_epochs = T, L, epochs
+        sim.render, sim.save_path, sim.save_freq, sim.save_gif_freq, sim.save_gif = False, ".", 500, float("inf"), False
+        sim.render_first_episode, sim.episode_count, sim.DEBUG = True, 0, False
+        sim.stat_buffers = {}
+        sim.agents = {i: Agent(i) for i in range(A)}
+        sim.loggers = {i: Logger(i) for i in range(A)}
+        sim.train()
+        out[name] = dict(A=A, global_critic=global_critic, T=T, L=L, epochs=epochs, seed=seed,
+                         draws=[[k, a0, a1, v] for (k, a0, a1, v) in rec.log], events=ev,
+                         episode_count=int(sim.episode_count))
+        print(name, len(ev), "events", sum(1 for e in ev if e[0] == "gae"), "trajectories",
+              sum(1 for e in ev if e[0] == "gae" and e[2] == 0.0), "terminal")
+    with open(os.path.join(OUT, "train_trace.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote train_trace.json")
+
+
+def gen_loss():
+    """SURVEY 8c fixture (5), row P6/P7: AgentPPO.update_rada2c (algos/multiagent/ppo.py:1150-1281) run as the
+    reference wrote it -- its PPO-clip / value / entropy loss, KL test, backward and Adam step -- on episodes of
+    our choosing, with the FF_core network (FF_core.py:42-129) standing behind agent.grad_step (the
+    2x64 MLP trained with the RAD-A2C loss form).  Captured: inputs, parameters before, loss / kl / entropy /
+    clip fraction / value loss, parameters after the step, and the early-stop decision for a batch that trips it."""
+    import types
+    import torch
+    from algos.multiagent import ppo as RP
+    from algos.multiagent.NeuralNetworkCores.FF_core import ActorCritic
+    from torch.distributions import Categorical
+
+    torch.manual_seed(23)
+    ac = ActorCritic(state_dim=11, action_dim=8, has_continuous_action_space=False, action_std_init=0.6)
+    rng = np.random.default_rng(31)
+    res = {}
+    for tag, scale in (("step", 1.0), ("stop", 40.0)):
+        lens = [int(x) for x in rng.integers(3, 21, size=6)]
+        eps = []
+        for n in lens:
+            obs = rng.normal(size=(n, 11)).astype(np.float32)
+            act = rng.integers(0, 8, size=n).astype(np.float32)
+            adv = rng.normal(size=n).astype(np.float32)
+            ret = rng.normal(size=n).astype(np.float32)
+            with torch.no_grad():
+                d = Categorical(ac.actor(torch.from_numpy(obs)))
+                logp_old = d.log_prob(torch.from_numpy(act)).numpy() + (rng.normal(size=n) * 0.05 * scale).astype(np.float32)
+            src = rng.uniform(0, 1, size=(n, 2)).astype(np.float32)
+            # column layout of the reference's episode form: obs 0:11 | adv 11 | ret 12 | logp 13 | act 14 | src 15:17
+            eps.append(np.concatenate([obs, adv[:, None], ret[:, None], logp_old[:, None], act[:, None], src], axis=1))
+        before = {k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+
+        class AgentShim:
+            pi = ac.actor
+
+            @staticmethod
+            def grad_step(obs, act, hidden=None):
+                probs = ac.actor(obs)
+                d = Categorical(probs)
+                return d, ac.critic(obs), d.log_prob(act), torch.zeros(obs.shape[0], 2)
+
+        opt = RP.OptimizationStorage(
+            critic_flag=False, pi_optimizer=torch.optim.Adam(ac.parameters(), lr=3e-4), critic_optimizer=None,
+            model_optimizer=torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=5e-3))
+        me = types.SimpleNamespace(minibatch=1, agent=AgentShim, agent_optimizer=opt, clip_ratio=0.2, alpha=0.1, target_kl=0.07,
+                                   env_height=5.0, reset_hidden=lambda: None)
+        np.random.seed(3)
+        order = np.random.choice(np.arange(0, len(eps)), size=len(eps), replace=False)    # what :1183 will draw
+        np.random.seed(3)
+        data = dict(ep_form=[[torch.from_numpy(e)] for e in eps])
+        loss, info, term, ploss = RP.AgentPPO.update_rada2c(me, data, min_iterations=len(eps), logger=None)
+        after = {k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+        # pi_optimizer.zero_grad() ran before loss_pi.backward() (:1253-1254): .grad still holds this call's gradients
+        grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad.detach().clone()).numpy() for k, v in ac.named_parameters()}
+        res.update({f"{tag}_grad_{k}": v for k, v in grads.items()})
+        res.update({f"{tag}_ep{i}": e for i, e in enumerate(eps)})
+        res.update({f"{tag}_before_{k}": v for k, v in before.items()})
+        res.update({f"{tag}_after_{k}": v for k, v in after.items()})
+        res[f"{tag}_order"] = order
+        res[f"{tag}_loss"] = np.float32(loss.item())
+        res[f"{tag}_kl"] = np.float32(info["kl"])
+        res[f"{tag}_ent"] = np.float32(info["ent"])
+        res[f"{tag}_cf"] = np.float32(info["cf"])
+        res[f"{tag}_val_loss"] = np.float32(info["val_loss"])
+        res[f"{tag}_term"] = np.bool_(term)
+        print(tag, "loss", loss.item(), "kl", float(info["kl"]), "term", term)
+    res["n_eps"] = np.int64(6)
+    np.savez_compressed(os.path.join(OUT, "rada2c_loss.npz"), **res)
+    print("wrote rada2c_loss.npz")
+
+
 if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn"]
+    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss"]
     if "env" in which:
         gen_env_scenarios()
     if "gae" in which:
@@ -447,3 +638,7 @@ if __name__ == "__main__":
         gen_maps()
     if "cnn" in which:
         gen_cnn()
+    if "train" in which:
+        gen_train_trace()
+    if "loss" in which:
+        gen_loss()

@@ -262,7 +262,7 @@ def _torch_loss_and_grads(ac, X, act, adv, ret, lpo, w, clip, alpha, vf=0.01):
     ratio = torch.exp(logp - lpo)
     surr = torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv)
     vl = (w * (v - ret) ** 2).sum()
-    loss = -((w * surr).sum() - vf * vl + alpha * (w * ent).sum())
+    loss = -((w * surr).sum() - vf * vl + alpha * (w * ent).sum().detach())     # ppo.py:1216: entropy is detached
     loss.backward()
     clipped = (ratio > 1 + clip) | (ratio < 1 - clip)
     stats = [(w * (lpo - logp)).sum().item(), (w * ent).sum().item(), (w * clipped.float()).sum().item(), vl.item(), loss.item()]
@@ -363,3 +363,42 @@ def test_obstacle_training_stays_finite():
                 nested = ((rect[k, 0] <= rect[i, 0]) & (rect[i, 0] <= rect[k, 2]) & (rect[k, 1] <= rect[i, 1])
                           & (rect[i, 1] <= rect[k, 3]) & live[i] & live[k])
                 assert not nested.any()
+
+
+def test_fused_grad_and_adam_step_match_reference_update_rada2c(golden_dir):
+    """rs_ppo_grad + rs_adam_step against the reference's own update_rada2c (algos/multiagent/ppo.py:1150-1281) run on
+    the FF_core network (tests/golden/rada2c_loss.npz): loss, approx-KL, entropy, clip fraction, value loss, every
+    parameter gradient, the KL early-stop decision and the parameters after the Adam step.
+    Tolerance: fp32, different summation order -- gradients rtol 2e-4 / atol 2e-7, scalars 2e-6."""
+    from radiation_ppo_amd.ppo import FFActorCritic, FusedPPOGrad
+    d = np.load(os.path.join(golden_dir, "rada2c_loss.npz"))
+    names = ["actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias", "actor.4.weight", "actor.4.bias",
+             "critic.0.weight", "critic.0.bias", "critic.2.weight", "critic.2.bias", "critic.4.weight", "critic.4.bias"]
+    for tag in ("step", "stop"):
+        ac = FFActorCritic().cuda()
+        ac.load_state_dict({k: torch.from_numpy(d[f"{tag}_before_{k}"]) for k in names})
+        eps = [torch.from_numpy(d[f"{tag}_ep{i}"]) for i in range(int(d["n_eps"]))]
+        E = len(eps)
+        cat = torch.cat(eps).cuda()
+        X, adv, ret, lpo = (cat[:, :11].contiguous(), cat[:, 11].contiguous(), cat[:, 12].contiguous(), cat[:, 13].contiguous())
+        act = cat[:, 14].long().contiguous()
+        w = torch.cat([torch.full((e.shape[0],), 1.0 / (E * e.shape[0])) for e in eps]).cuda()
+        f = FusedPPOGrad(ac)
+        f.begin_update()
+        stats, grads = f(X, act, adv, ret, lpo, w, 0.2, 0.1, use_stop_flag=True)
+        st = stats.cpu().numpy()
+        assert abs(st[0] - float(d[f"{tag}_kl"])) < 2e-6 and abs(st[1] - float(d[f"{tag}_ent"])) < 2e-6
+        assert abs(st[2] - float(d[f"{tag}_cf"])) < 2e-6 and abs(st[3] - float(d[f"{tag}_val_loss"])) < 2e-6
+        assert abs(st[4] - float(d[f"{tag}_loss"])) < 2e-6
+        term = bool(d[f"{tag}_term"])
+        if not term:
+            for (p, g), k in zip(f.views, names):
+                assert np.allclose(g.cpu().numpy(), d[f"{tag}_grad_{k}"], rtol=2e-4, atol=2e-7), (tag, k)
+        f.adam_step(3e-4, 1.5 * 0.07)
+        iters, stopped, adam_t, _ = f.read_state()
+        assert bool(stopped) == term and adam_t == (0 if term else 1)
+        for k, p in zip(names, [dict(ac.named_parameters())[k] for k in names]):
+            got, want = p.detach().cpu().numpy(), d[f"{tag}_after_{k}"]
+            big = np.abs(d[f"{tag}_grad_{k}"]) > 1e-5 if not term else np.ones_like(want, dtype=bool)
+            assert np.allclose(got[big], want[big], rtol=0, atol=3e-6), (tag, k, np.abs(got - want)[big].max())
+            assert np.abs(got - want).max() <= 6.1e-4, (tag, k)
