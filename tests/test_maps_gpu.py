@@ -155,3 +155,73 @@ def test_cnn_collector_replays_through_oracles():
                 steps = 0
     res = col.update()
     assert np.isfinite(res[0].loss_policy) and np.isfinite(res[0].loss_critic)
+
+
+def test_cnn_collector_follows_the_pinned_train_loop():
+    """The product collector against oracle/train_loop_oracle.train_loop_trace -- the restatement that
+    tests/test_train_loop_golden.py pins to the reference's own train() -- env by env: the trace is driven with
+    the actions / values the device stored and must reproduce what the device stored for every store() call
+    (observation, team reward, value, terminal flag), every GAE bootstrap value and the episode statistics."""
+    from oracle.train_loop_oracle import train_loop_trace
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L = 16, 2, 36, 10
+    torch.manual_seed(5)
+    env = RadSearchVec(N, number_agents=A, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED)
+    gc = CNNCritic().cuda()
+    gco = torch.optim.Adam(gc.parameters(), lr=1e-3)
+    agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=2, train_v_iters=2) for i in range(A)}
+    col = CNNCollector(env, agents, T, L, global_critic_flag=True)
+    stats = col.collect()
+    buf = col.buf
+    obs, act, rew, val, logp, cut, lastv = (x.cpu().numpy() for x in (buf.obs, buf.act, buf.rew, buf.val, buf.logp, buf.cut, buf.last_val))
+    ep_ret_sum, ep_len_sum, ep_cnt = 0.0, 0.0, 0
+    for n in range(N):
+        ref = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=A, obstruction_count=0, enforce_grid_boundaries=True)
+        st = {"t": 0, "after_step": False}
+
+        class Env:                                   # train() begins with env.reset(): the constructor's reset stands for it
+            first = True
+            src = property(lambda s: ref.src)
+
+            def reset(s):
+                st["after_step"] = False
+                if Env.first:
+                    Env.first = False
+                    return ref._ret
+                return ref.reset()
+
+            def step(s, a):
+                r = ref.step(a)
+                st["t"] += 1
+                st["after_step"] = True
+                return r
+
+            def __setattr__(s, k, v):
+                setattr(ref, k, v)
+
+        def agent_step(i, observations):
+            if st["after_step"] and cut[st["t"] - 1, n, 0]:      # the bootstrap round (train.py:476-480)
+                return 0, float(lastv[st["t"] - 1, n, i]), 0.0
+            t = st["t"]
+            return int(act[t, n, i]), float(val[t, n, i]), float(logp[t, n, i])
+
+        ev, _ = train_loop_trace(Env(), agent_step, A, True, T, L, 1)
+        stores = [e for e in ev if e[0] == "store"]
+        assert len(stores) == T * A
+        for k, e in enumerate(stores):
+            t, i = divmod(k, A)
+            assert np.array_equal(obs[t, n, i], np.asarray(e[2], dtype=np.float64).astype(np.float32)), (n, t, i)
+            assert rew[t, n, i] == np.float32(e[3]) and bool(cut[t, n, i]) == e[8], (n, t, i)
+        # zero bootstrap exactly where the trace says the trajectory ended on a terminal
+        gae = [e for e in ev if e[0] == "gae"]
+        cuts_t = [t for t in range(T) if cut[t, n, 0]]
+        assert len(gae) == len(cuts_t) * A
+        for k, e in enumerate(gae):
+            assert float(lastv[cuts_t[k // A], n, e[1]]) == e[2]
+        ep_ret_sum += sum(e[3] for e in ev if e[0] == "log" and e[1] == 0 and e[2] == "EpRet")
+        ep_len_sum += sum(e[3] for e in ev if e[0] == "log" and e[1] == 0 and e[2] == "EpLen")
+        ep_cnt += sum(1 for e in ev if e[0] == "ep_len" and e[1] == 0)
+    assert int(stats["EpCount"].item()) == ep_cnt and float(stats["EpLenSum"].item()) == ep_len_sum
+    assert abs(float(stats["EpRetSum"].item()) - ep_ret_sum) < 1e-4
