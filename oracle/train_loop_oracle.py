@@ -13,14 +13,26 @@ own update_rada2c with the FF_core network behind it (gen_loss).
 import numpy as np
 
 
-def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per_epoch, steps_per_episode, total_epochs):
-    """Event trace of train_PPO.train for the 'cnn' architecture branch (no RAD-A2C standardisation side calls).
+def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per_epoch, steps_per_episode, total_epochs,
+                     arch="cnn"):
+    """Event trace of train_PPO.train.  arch='cnn': RAD-TEAM branch.  arch='mlp'/'rnn': the RAD-A2C branch, which
+    standardises observation[0] IN PLACE with a per-episode StatisticStandardization (train.py:306-311, :334-341,
+    :437-441, :462-471, :504-509, :543-548) -- the branch the 2x64 MLP ('ff') collector of the build follows.
 
     env: an object with reset()/step(dict)/epoch_end/src (oracle.radsearch_oracle.RadSearchOracle).
     agent_step(id, observations) -> (action, state_value, logp): what ac.step returns (:349-357, :476-480).
     Returns the list of events in the order train() produces them (same vocabulary as the golden file)."""
+    from oracle.radsearch_oracle import WelfordOracle
     A = number_of_agents
     ev = []
+    a2c = arch in ("mlp", "rnn")
+    stat = {i: WelfordOracle() for i in range(A)} if a2c else {}
+
+    def standardize_in_place(observations):
+        for i in range(A):
+            o = list(observations[i])
+            o[0] = stat[i].standardize(o[0])
+            observations[i] = o
     f64 = lambda o: np.asarray(o, dtype=np.float64).tolist()
 
     def do_reset():
@@ -39,8 +51,16 @@ def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per
     oob_count = {i: 0 for i in range(A)}
     terminal_counter = {i: 0 for i in range(A)}
     episode_count = 0
+    if a2c:                                                                         # :306-311
+        for i in range(A):
+            stat[i].update(observations[i][0])
     for epoch in range(total_epochs):
+        if a2c:                                                                     # :322-330
+            for i in range(A):
+                ev.append(["reset_hidden", i])
         for steps_in_epoch in range(steps_per_epoch):
+            if a2c:                                                                 # :334-341
+                standardize_in_place(observations)
             thoughts = {i: do_agent(i, observations) for i in range(A)}            # :347-357
             actions = {i: int(thoughts[i][0]) for i in range(A)}
             ev.append(["env_step", {str(k): v for k, v in actions.items()}])
@@ -65,10 +85,14 @@ def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per
                 r = rewards["individual_reward"][i] if not global_critic else rewards["team_reward"]
                 ev.append(["store", i, f64(observations[i]), float(r), actions[i], float(thoughts[i][1]), float(thoughts[i][2]),
                            [float(np.float32(src[0])), float(np.float32(src[1]))], bool(reset_next)])
+                if a2c:                                                             # :437-441 (inside the agent loop)
+                    stat[i].update(next_observations[i][0])
             observations = next_observations                                        # :446-449
             if reset_next:                                                          # :453
                 episode_count += 1
                 if timeout or epoch_ended:                                          # :466-484
+                    if a2c:
+                        standardize_in_place(observations)
                     last_val = [do_agent(i, observations)[1] for i in range(A)]
                     if epoch_ended:
                         ev.append(["epoch_end_set", True])
@@ -82,6 +106,12 @@ def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per
                         ev.append(["log", i, "EpRet", float(episode_return[i])])
                         ev.append(["log", i, "EpLen", float(steps_in_episode)])
                         ev.append(["ep_len", i, steps_in_episode])
+                if a2c:                                                             # :504-509
+                    for i in range(A):
+                        stat[i].reset()
+                if a2c and not epoch_ended:                                         # :512-517
+                    for i in range(A):
+                        ev.append(["reset_hidden", i])
                 if epoch_ended:                                                     # :519-526
                     for i in range(A):
                         ev.append(["log", i, "DoneCount", float(terminal_counter[i])])
@@ -92,8 +122,12 @@ def train_loop_trace(env, agent_step, number_of_agents, global_critic, steps_per
                 src = [float(env.src[0]), float(env.src[1])]
                 episode_return = {i: 0 for i in range(A)}
                 steps_in_episode = 0
-                for i in range(A):
-                    ev.append(["reset_agent", i])                                   # :537-540
+                if arch == "cnn":
+                    for i in range(A):
+                        ev.append(["reset_agent", i])                               # :537-540
+                if a2c:                                                             # :543-548
+                    for i in range(A):
+                        stat[i].update(observations[i][0])
         if (epoch % 500 == 0) or (epoch == total_epochs - 1):                      # :552-561 (save_freq default)
             for i in range(A):
                 ev.append(["save", i])

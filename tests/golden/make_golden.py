@@ -440,8 +440,10 @@ def gen_train_trace():
     from algos.multiagent import train as RT
 
     out = {}
-    for name, A, global_critic, T, L, epochs, seed in (("a1_individual", 1, False, 50, 18, 3, 5),
-                                                        ("a2_team", 2, True, 44, 16, 3, 9)):
+    from algos.multiagent.NeuralNetworkCores.RADTEAM_core import StatisticStandardization
+    for name, A, global_critic, T, L, epochs, seed, arch in (("a1_individual", 1, False, 50, 18, 3, 5, "cnn"),
+                                                              ("a2_team", 2, True, 44, 16, 3, 9, "cnn"),
+                                                              ("a1_mlp_standardized", 1, False, 58, 20, 3, 13, "mlp")):
         rec = RecordingGenerator(seed)
         env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0, enforce_grid_boundaries=True)
         ev = []
@@ -493,6 +495,14 @@ def gen_train_trace():
             def reset_agent(self_):
                 ev.append(["reset_agent", self_.id])
 
+            # RAD-A2C branch plumbing touched by train() (:311, :327-330, :516): no effect on the control flow
+            agent = types.SimpleNamespace(model=types.SimpleNamespace(eval=lambda: None), pi=types.SimpleNamespace(
+                logits_net=types.SimpleNamespace(v_net=types.SimpleNamespace(eval=lambda: None))))
+
+            def reset_hidden(self_):
+                ev.append(["reset_hidden", self_.id])
+                return None
+
             def reduce_pfgru_training(self_):
                 ev.append(["reduce_pfgru", self_.id])
 
@@ -525,20 +535,23 @@ def gen_train_trace():
             def log(self_, *a, **k):
                 pass
 
+            def save_state(self_, *a, **k):
+                ev.append(["save", self_.id])
+
         sim = object.__new__(RT.train_PPO)      # skip __post_init__ (builds the real agents / loggers)
         sim.env = EnvProxy()
         sim.logger_kwargs = dict(data_dir=".", env_name="x", exp_name="x", seed=0)
         sim.ppo_kwargs = {}
         sim.seed, sim.number_of_agents = 0, A
-        sim.actor_critic_architecture, sim.global_critic_flag = "cnn", global_critic
+        sim.actor_critic_architecture, sim.global_critic_flag = arch, global_critic
         sim.steps_per_epoch, sim.steps_per_episode, sim.total_epochs = T, L, epochs
         sim.render, sim.save_path, sim.save_freq, sim.save_gif_freq, sim.save_gif = False, ".", 500, float("inf"), False
         sim.render_first_episode, sim.episode_count, sim.DEBUG = True, 0, False
-        sim.stat_buffers = {}
+        sim.stat_buffers = {i: StatisticStandardization() for i in range(A)} if arch == "mlp" else {}
         sim.agents = {i: Agent(i) for i in range(A)}
         sim.loggers = {i: Logger(i) for i in range(A)}
         sim.train()
-        out[name] = dict(A=A, global_critic=global_critic, T=T, L=L, epochs=epochs, seed=seed,
+        out[name] = dict(A=A, global_critic=global_critic, T=T, L=L, epochs=epochs, seed=seed, arch=arch,
                          draws=[[k, a0, a1, v] for (k, a0, a1, v) in rec.log], events=ev,
                          episode_count=int(sim.episode_count))
         print(name, len(ev), "events", sum(1 for e in ev if e[0] == "gae"), "trajectories",

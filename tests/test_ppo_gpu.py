@@ -102,35 +102,7 @@ def test_collector_rollout_replays_through_oracle():
     col = Collector(env, agents, T, L)
     col.collect()
     buf = col.buf
-    obs, act, rew, cut = (t.cpu().numpy() for t in (buf.obs, buf.act, buf.rew, buf.cut))
-    lastv = buf.last_val.cpu().numpy()
-    for n in range(0, N, 3):
-        e = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=1, obstruction_count=2, enforce_grid_boundaries=True)
-        st = WelfordOracle()
-        o = e._ret[0][0]
-        st.update(o[0])
-        steps = 0
-        for t in range(T):
-            x = np.array(o, dtype=np.float64)
-            x[0] = st.standardize(o[0])
-            assert np.allclose(obs[t, n, 0], x.astype(np.float32), rtol=2e-7, atol=1e-7), (n, t)
-            ro, rr, rd, _ = e.step({0: int(act[t, n, 0])})
-            assert rew[t, n, 0] == np.float32(rr["individual_reward"][0]), (n, t)
-            steps += 1
-            o = ro[0]
-            st.update(o[0])
-            over = rd[0] or steps == L
-            expect_cut = over or t == T - 1
-            assert bool(cut[t, n, 0]) == expect_cut, (n, t)
-            if expect_cut:
-                if rd[0] and not (steps == L or t == T - 1):
-                    assert lastv[t, n, 0] == 0.0
-                if t == T - 1:
-                    e.epoch_end = True
-                st.reset()
-                o = e.reset()[0][0]
-                st.update(o[0])
-                steps = 0
+    _replay_check(col, agents, N, T, L, 2)
     # logp / val stored by the collector == re-evaluation of the same network on the stored inputs
     X = buf.obs[:, :, 0].reshape(-1, 11)
     with torch.no_grad():
@@ -182,38 +154,59 @@ def test_mfma_policy_forward_vs_torch_and_reference(golden_dir):
 
 
 def _replay_check(col, agents, N, T, L, obst, stride=3):
+    """Drive oracle/train_loop_oracle.train_loop_trace (RAD-A2C branch; pinned to the reference's own train() by
+    tests/test_train_loop_golden.py) with the actions / values the device stored, env by env, and require the
+    device buffer to hold what the trace passes to store(): standardised observation (float64 Welford, within 1 ulp
+    of float32), reward, source target, terminal flag -- and a zero bootstrap exactly on terminal trajectories."""
+    from oracle.train_loop_oracle import train_loop_trace
     buf = col.buf
-    obs, act, rew, cut = (t.cpu().numpy() for t in (buf.obs, buf.act, buf.rew, buf.cut))
+    obs, act, rew, cut, val, logp = (t.cpu().numpy() for t in (buf.obs, buf.act, buf.rew, buf.cut, buf.val, buf.logp))
     lastv = buf.last_val.cpu().numpy()
     src = buf.source_tar.cpu().numpy()
     for n in range(0, N, stride):
-        e = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=1, obstruction_count=obst, enforce_grid_boundaries=True)
-        st = WelfordOracle()
-        o = e._ret[0][0]
-        st.update(o[0])
-        steps = 0
-        for t in range(T):
-            x = np.array(o, dtype=np.float64)
-            x[0] = st.standardize(o[0])
-            assert np.allclose(obs[t, n, 0], x.astype(np.float32), rtol=2e-7, atol=1e-7), (n, t, obs[t, n, 0], x)
-            assert tuple(src[t, n]) == (float(e.src[0]), float(e.src[1])), (n, t)
-            ro, rr, rd, _ = e.step({0: int(act[t, n, 0])})
-            assert rew[t, n, 0] == np.float32(rr["individual_reward"][0]), (n, t)
-            steps += 1
-            o = ro[0]
-            st.update(o[0])
-            over = rd[0] or steps == L
-            expect_cut = over or t == T - 1
-            assert bool(cut[t, n, 0]) == expect_cut, (n, t)
-            if expect_cut:
-                if rd[0] and not (steps == L or t == T - 1):
-                    assert lastv[t, n, 0] == 0.0
-                if t == T - 1:
-                    e.epoch_end = True
-                st.reset()
-                o = e.reset()[0][0]
-                st.update(o[0])
-                steps = 0
+        ref = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=1, obstruction_count=obst, enforce_grid_boundaries=True)
+        st = {"t": 0, "after_step": False, "first": True}
+
+        class Env:
+            src = property(lambda s: ref.src)
+
+            def reset(s):
+                st["after_step"] = False
+                if st["first"]:                      # train() opens with env.reset(): the constructor's reset stands for it
+                    st["first"] = False
+                    return ref._ret
+                return ref.reset()
+
+            def step(s, a):
+                r = ref.step(a)
+                st["t"] += 1
+                st["after_step"] = True
+                return r
+
+            def __setattr__(s, k, v):
+                setattr(ref, k, v)
+
+        def agent_step(i, observations):
+            if st["after_step"] and cut[st["t"] - 1, n, 0]:          # bootstrap call (train.py:476-480)
+                return 0, float(lastv[st["t"] - 1, n, 0]), 0.0
+            t = st["t"]
+            return int(act[t, n, 0]), float(val[t, n, 0]), float(logp[t, n, 0])
+
+        ev, _ = train_loop_trace(Env(), agent_step, 1, False, T, L, 1, arch="mlp")
+        stores = [e for e in ev if e[0] == "store"]
+        assert len(stores) == T
+        for t, e in enumerate(stores):
+            x = np.asarray(e[2], dtype=np.float64).astype(np.float32)
+            assert np.allclose(obs[t, n, 0], x, rtol=2e-7, atol=1e-7), (n, t, obs[t, n, 0], x)
+            assert tuple(float(v) for v in src[t, n]) == tuple(e[7]), (n, t)
+            assert rew[t, n, 0] == np.float32(e[3]), (n, t)
+            assert bool(cut[t, n, 0]) == e[8], (n, t)
+        gae = [e for e in ev if e[0] == "gae"]
+        cuts_t = [t for t in range(T) if cut[t, n, 0]]
+        assert len(gae) == len(cuts_t)
+        for t, e in zip(cuts_t, gae):
+            assert float(lastv[t, n, 0]) == e[2], (n, t)             # 0.0 where the trace ended on a terminal
+        assert ref.err == 0
 
 
 @pytest.mark.parametrize("obst", [0, 3])

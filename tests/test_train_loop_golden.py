@@ -24,7 +24,7 @@ def _rows(draws):
     return rows
 
 
-@pytest.mark.parametrize("name", ["a1_individual", "a2_team"])
+@pytest.mark.parametrize("name", ["a1_individual", "a2_team", "a1_mlp_standardized"])
 def test_train_control_flow_matches_reference_trace(golden_dir, name):
     with open(os.path.join(golden_dir, "train_trace.json")) as f:
         g = json.load(f)[name]
@@ -42,7 +42,7 @@ def test_train_control_flow_matches_reference_trace(golden_dir, name):
 
     env = RadSearchOracle(ReplayDraws(_rows(g["draws"])), number_agents=g["A"], obstruction_count=0,
                           enforce_grid_boundaries=True)
-    got, episodes = train_loop_trace(env, agent_step, g["A"], g["global_critic"], g["T"], g["L"], g["epochs"])
+    got, episodes = train_loop_trace(env, agent_step, g["A"], g["global_critic"], g["T"], g["L"], g["epochs"], arch=g["arch"])
     assert episodes == g["episode_count"]
     assert len(got) == len(want)
     for k, (a, b) in enumerate(zip(got, want)):
