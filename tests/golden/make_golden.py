@@ -632,11 +632,56 @@ def gen_loss():
     print("wrote rada2c_loss.npz")
 
 
+def gen_cnn_loss():
+    """Row P6, CNN branch: AgentPPO.compute_batched_losses_pi / compute_loss_pi (algos/multiagent/ppo.py:903-997) and
+    compute_batched_losses_critic / compute_loss_critic (:999-1045) as the reference wrote them, over the reference's
+    CNN Actor / Critic (RADTEAM_core.py:935-1345): losses, diagnostics and parameter gradients for a fixed batch."""
+    import types
+    import torch
+    from algos.multiagent import ppo as RP
+    from algos.multiagent.NeuralNetworkCores import RADTEAM_core as R
+    torch.manual_seed(17)
+    actor = R.Actor(map_dim=(27, 27), action_dim=8)
+    critic = R.Critic(map_dim=(27, 27))
+    rng = np.random.default_rng(19)
+    n = 14
+    xa = (rng.random((n, 1, 6, 27, 27)) * (rng.random((n, 1, 6, 27, 27)) < 0.05)).astype(np.float32)
+    xc = (rng.random((n, 1, 4, 27, 27)) * (rng.random((n, 1, 4, 27, 27)) < 0.05)).astype(np.float32)
+    act = torch.from_numpy(rng.integers(0, 8, size=n))
+    adv = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    with torch.no_grad():
+        lp = torch.stack([actor.get_action_information(torch.from_numpy(xa[i]), act[i])[0] for i in range(n)]).reshape(-1)
+    logp_old = lp + torch.from_numpy((rng.normal(size=n) * 0.3).astype(np.float32))
+    data = dict(obs=torch.zeros(n, 11), act=act, adv=adv, logp=logp_old, ret=ret)
+    me = types.SimpleNamespace(actor_critic_architecture="cnn", clip_ratio=0.2, reset_agent=lambda: None,
+                               agent=types.SimpleNamespace(pi=actor, critic=critic, mseLoss=torch.nn.MSELoss()))
+    me.compute_loss_pi = lambda **kw: RP.AgentPPO.compute_loss_pi(me, **kw)
+    me.compute_loss_critic = lambda **kw: RP.AgentPPO.compute_loss_critic(me, **kw)
+    sample = list(range(n))
+    pi = RP.AgentPPO.compute_batched_losses_pi(me, sample=sample, data=data, mapstacks_buffer=[torch.from_numpy(x) for x in xa])
+    pi["pi_loss"].backward()
+    cr = RP.AgentPPO.compute_batched_losses_critic(me, data=data, map_buffer_maps=[torch.from_numpy(x) for x in xc], sample=sample)
+    cr["critic_loss"].backward()
+    out = dict(xa=xa, xc=xc, act=act.numpy(), adv=adv.numpy(), ret=ret.numpy(), logp_old=logp_old.numpy(),
+               pi_loss=np.float32(pi["pi_loss"].item()), kl=np.float64(pi["kl"]), entropy=np.float64(pi["entropy"]),
+               clip_fraction=np.float64(pi["clip_fraction"]), critic_loss=np.float32(cr["critic_loss"].item()))
+    # (the reference modules also carry unused debugging copies `step1..step7` of the layers: not saved)
+    out.update({"a_" + k: v.numpy() for k, v in actor.state_dict().items() if k.startswith("actor.")})
+    out.update({"c_" + k: v.numpy() for k, v in critic.state_dict().items() if k.startswith("critic.")})
+    none = [k for k, v in list(actor.named_parameters()) + list(critic.named_parameters()) if v.grad is None]
+    print("parameters without gradient:", none)
+    out.update({"ga_" + k: v.grad.numpy() for k, v in actor.named_parameters() if v.grad is not None})
+    out.update({"gc_" + k: v.grad.numpy() for k, v in critic.named_parameters() if v.grad is not None})
+    np.savez_compressed(os.path.join(OUT, "cnn_loss.npz"), **out)
+    print("wrote cnn_loss.npz", float(out["pi_loss"]), float(out["kl"]), float(out["clip_fraction"]), float(out["critic_loss"]))
+
+
 if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss"]
+    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss"]
     if "env" in which:
         gen_env_scenarios()
     if "gae" in which:
@@ -655,3 +700,5 @@ if __name__ == "__main__":
         gen_train_trace()
     if "loss" in which:
         gen_loss()
+    if "cnnloss" in which:
+        gen_cnn_loss()

@@ -225,3 +225,29 @@ def test_cnn_collector_follows_the_pinned_train_loop():
         ep_cnt += sum(1 for e in ev if e[0] == "ep_len" and e[1] == 0)
     assert int(stats["EpCount"].item()) == ep_cnt and float(stats["EpLenSum"].item()) == ep_len_sum
     assert abs(float(stats["EpRetSum"].item()) - ep_ret_sum) < 1e-4
+
+
+def test_cnn_update_losses_and_gradients_match_reference(golden_dir):
+    """CNNAgentPPO.update_agent (one actor iteration, one critic iteration, lr 0) against the reference's own
+    compute_batched_losses_pi / compute_batched_losses_critic (algos/multiagent/ppo.py:903-1045) on the reference CNNs
+    (tests/golden/cnn_loss.npz): policy loss, approx-KL, entropy, clip fraction, critic MSE and every parameter
+    gradient.  Tolerance fp32 rtol 2e-4 / atol 1e-6 (MIOpen convolutions vs the reference's CPU kernels)."""
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO
+    g = dict(np.load(os.path.join(golden_dir, "cnn_loss.npz")).items())
+    ag = CNNAgentPPO(id=0, train_pi_iters=1, train_v_iters=1, actor_learning_rate=0.0, critic_learning_rate=0.0, target_kl=10.0)
+    ag.pi.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("a_actor.")})
+    ag.critic.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("c_critic.")})
+    xa, xc = torch.from_numpy(g["xa"][:, 0]).cuda(), torch.from_numpy(g["xc"][:, 0]).cuda()
+    n = xa.shape[0]
+    dev = lambda k, dt=None: torch.from_numpy(g[k]).cuda() if dt is None else torch.from_numpy(g[k]).cuda().to(dt)
+    w = torch.full((n,), 1.0 / n, device="cuda")
+    r = ag.update_agent(lambda lo, hi: xa[lo:hi], lambda lo, hi: xc[lo:hi], dev("act", torch.int64), dev("adv"), dev("ret"),
+                        dev("logp_old"), w, update_critic=True)
+    assert r.stop_iteration == 1
+    assert abs(r.loss_policy - float(g["pi_loss"])) < 2e-6 and abs(r.kl_divergence - float(g["kl"])) < 2e-6
+    assert abs(r.Entropy - float(g["entropy"])) < 2e-6 and abs(r.ClipFrac - float(g["clip_fraction"])) < 1e-7
+    assert abs(r.loss_critic - float(g["critic_loss"])) < 2e-6
+    for k, p in ag.pi.named_parameters():
+        assert np.allclose(p.grad.cpu().numpy(), g["ga_" + k], rtol=2e-4, atol=1e-6), k
+    for k, p in ag.critic.named_parameters():
+        assert np.allclose(p.grad.cpu().numpy(), g["gc_" + k], rtol=2e-4, atol=1e-6), k
