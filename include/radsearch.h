@@ -253,6 +253,28 @@ int rs_maps_stack(rs_maps* m, float* actor_stack, float* critic_stack, rs_stream
 /* introspection for tests: "pred_cell","cell" ([N,A] int32), "combined","readings","visits","obstacles" ([N,X*Y] f32) */
 int rs_maps_field(rs_maps* m, const char* name, void** dev_ptr, int32_t* elem_bytes, int32_t* rows, int32_t* cols);
 
+/* ---- RAD-TEAM CNN trunk (NeuralNetworkCores/RADTEAM_core.py:962-1023 Actor, :1211-1271 Critic) ----------------
+ * conv3x3(Cin->8, pad 1) - ReLU - maxpool 2x2/2 - conv3x3(8->16, pad 1) - ReLU - Flatten on 27x27 maps, forward and
+ * weight-gradient backward, reading the resident shared maps directly (replaces actor[0:6] / critic[0:6] of the
+ * nn.Sequential and their autograd for a whole batch; the three Linear layers after it stay library GEMMs).
+ *   maps   [S][4][729] float32: combined, readings, visits, obstacles of each sample
+ *   agent >= 0: actor input (6 channels, CNNBase.get_map_stack :1791-1836) = {one-hot(pcells[s][agent]) or empty when
+ *               -1, one-hot(cells[s][agent]), combined - location, readings, visits, obstacles}; cells/pcells [S][A] int64
+ *   agent  < 0: critic input (4 channels) = maps as they are; cells/pcells ignored
+ *   w1 [8][Cin][3][3], b1 [8], w2 [16][8][3][3], b2 [16]: torch Conv2d layouts
+ *   a2 [S][2704] (= Flatten of the ReLU'd conv2 output); p1 [S][8][169] and amax [S][8][169] (pooled activations and
+ *   the winning pixel of each 2x2 window) are written when non-NULL (both or neither) and are what backward consumes.
+ * Backward: da2 [S][2704] = dL/d(a2); slab [rs_cnn_trunk_slab_rows(S)][rs_cnn_trunk_slab_row(Cin)] receives
+ * per-workgroup partial sums laid out {dW1 8*Cin*9 | db1 8 | dW2 1152 | db2 16}; the caller sums the rows. */
+int32_t rs_cnn_trunk_slab_row(int32_t in_channels);
+int32_t rs_cnn_trunk_slab_rows(int64_t num_samples);
+int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
+                         int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
+                         float* p1, uint8_t* amax, rs_stream_t stream);
+int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
+                          int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
+                          const uint8_t* amax, float* slab, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

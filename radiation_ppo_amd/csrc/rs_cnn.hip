@@ -1,0 +1,398 @@
+// rs_cnn.hip -- K9/K10: the convolutional trunk of the RAD-TEAM CNN actor / critic
+// (algos/multiagent/NeuralNetworkCores/RADTEAM_core.py:962-1023 Actor, :1211-1271 Critic):
+//     conv3x3(Cin->8, pad 1) - ReLU - maxpool 2x2/2 - conv3x3(8->16, pad 1) - ReLU - flatten(2704)
+// forward and backward, straight from the resident heat maps.  The channel counts (6/4 -> 8 -> 16) are far too
+// small for an implicit-GEMM library convolution (MIOpen spends minutes tuning and then runs at ~5 % of the f32
+// peak on these shapes), so the trunk is written directly:
+//   * one image per 192-thread workgroup at a time, the whole image in LDS (zero-padded planes), workgroups
+//     stride over the batch (persistent grid);
+//   * the input stack is never materialised in HBM: the 4 shared maps of a sample are read once (11.7 KB) and
+//     the owner's location / prediction one-hots and `others = combined - location`
+//     (CNNBase.get_map_stack, RADTEAM_core.py:1791-1836) are formed in LDS;
+//   * conv1 is evaluated per POOLED cell (thread = cell: a 4x4 input window per channel in registers feeds the
+//     2x2 block of conv outputs, 8 channels each -> 32 accumulators), so ReLU + max-pool happen in registers;
+//     row/column 26 of the conv1 output never reach the pool (27 = 2*13 + 1) and are not computed;
+//   * conv2: thread = output pixel, 16 accumulators;
+//   * weights are staged in LDS once per workgroup and read as wave-uniform (broadcast) float4s;
+//   * backward: dP1 = conv2^T(dZ2) on the VALU (thread = pixel), dW2 = dZ2 x patches(P1) on the matrix cores
+//     (v_mfma_f32_16x16x4_f32, contraction over the 169 pixels, accumulators live across all images of the
+//     workgroup), dW1 through the pool's argmax: only one of the four conv1 pixels of a cell carries gradient, so
+//     dW1 costs 8*169*Cin*9 MACs per image instead of 8*676*Cin*9; per-workgroup partial sums go to a slab that
+//     the caller reduces (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/radsearch.h"
+
+namespace {
+
+constexpr int CNN_NT = 192;                 // threads per workgroup (3 waves); 169 of them own a pooled cell / pixel
+constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
+constexpr int PW = 13, PC = 169;            // pooled side and cells
+constexpr int XP_RS = 28, XP_PLANE = 28 * 28;   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
+                                                // border only feeds conv1 row/column 26, which the pool drops; even stride (b64 reads)
+constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
+constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct CnnIn {
+    const float* maps;        // [S][4][729]: combined, readings, visits, obstacles
+    const int64_t* cells;     // [S][A] owner cells (actor) or nullptr (critic)
+    const int64_t* pcells;    // [S][A] prediction cell or -1
+    int A, agent;
+    long long S;
+};
+
+// ---- stage one sample's input planes in LDS; returns the one-hot cells the caller must clear afterwards
+template <int CIN>
+__device__ __forceinline__ void cnn_load_input(const CnnIn& in, long long s, float* xp, int& loc, int& pc) {
+    const float* src = in.maps + (size_t)s * 4 * MAPC;
+    constexpr int CH0 = (CIN == 6) ? 2 : 0;
+    for (int e = threadIdx.x; e < 4 * MAPC; e += CNN_NT) {
+        const int m = e / MAPC, q = e - m * MAPC;
+        const int r = q / MAPW, c = q - r * MAPW;
+        xp[(CH0 + m) * XP_PLANE + (r + 1) * XP_RS + (c + 1)] = src[e];
+    }
+    loc = -1; pc = -1;
+    if (CIN == 6) {
+        loc = (int)in.cells[(size_t)s * in.A + in.agent];
+        pc = (int)in.pcells[(size_t)s * in.A + in.agent];
+    }
+    __syncthreads();
+    if (CIN == 6 && threadIdx.x == 0) {
+        const int lr = loc / MAPW, lc = loc - lr * MAPW;
+        xp[1 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] = 1.0f;          // location map
+        xp[2 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] -= 1.0f;         // others = combined - location
+        if (pc >= 0) {
+            const int pr = pc / MAPW, pcc = pc - pr * MAPW;
+            xp[0 * XP_PLANE + (pr + 1) * XP_RS + pcc + 1] = 1.0f;      // prediction map
+        }
+    }
+    __syncthreads();
+}
+
+template <int CIN>
+__device__ __forceinline__ void cnn_clear_onehots(float* xp, int loc, int pc) {
+    if (CIN == 6 && threadIdx.x == 0) {
+        const int lr = loc / MAPW, lc = loc - lr * MAPW;
+        xp[1 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] = 0.0f;
+        if (pc >= 0) {
+            const int pr = pc / MAPW, pcc = pc - pr * MAPW;
+            xp[0 * XP_PLANE + (pr + 1) * XP_RS + pcc + 1] = 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 forward: maps -> a2 [S][2704] (post-ReLU conv2 output, torch Flatten order c*169 + y*13 + x), and for
+// training p1 [S][8][169] (pooled activations) + amax [S][8][169] (which pixel of the 2x2 window won, 0..3 in
+// row-major order; first maximum wins like torch's CPU max_pool2d).
+template <int CIN>
+__global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ a2, float* __restrict__ p1g,
+                                                            uint8_t* __restrict__ amax) {
+    extern __shared__ __align__(16) float smem[];
+    float* xp = smem;                               // [CIN][28][28]
+    float* pp = xp + CIN * XP_PLANE;                // [8][15][15]
+    float* w1s = pp + C1 * PP_PLANE;                // [(ci,ky,kx)][8] + b1[8]
+    float* w2s = w1s + (CIN * 9 + 1) * C1;          // [(ci,ky,kx)][16] + b2[16]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;     // borders stay zero
+    for (int e = tid; e < CIN * 9 * C1; e += CNN_NT) {           // torch [co][ci][ky][kx] -> [(ci,ky,kx)][co]
+        const int co = e / (CIN * 9), k = e - co * (CIN * 9);
+        w1s[k * C1 + co] = w1[e];
+    }
+    if (tid < C1) w1s[CIN * 9 * C1 + tid] = b1[tid];
+    for (int e = tid; e < C2 * C1 * 9; e += CNN_NT) {
+        const int co = e / (C1 * 9), k = e - co * (C1 * 9);
+        w2s[k * C2 + co] = w2[e];
+    }
+    if (tid < C2) w2s[C1 * 9 * C2 + tid] = b2[tid];
+    __syncthreads();
+    const int py = tid / PW, px = tid - py * PW;
+    const bool own = tid < PC;
+    for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
+        int loc, pc;
+        cnn_load_input<CIN>(in, s, xp, loc, pc);
+        if (own) {
+            // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
+            float acc[4][C1];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int co = 0; co < C1; ++co) acc[p][co] = 0.0f;
+#pragma unroll 1       // one input channel at a time: bounds the live broadcast weights (18 float4) and the window
+            for (int ci = 0; ci < CIN; ++ci) {
+                float win[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 a = *reinterpret_cast<const float2*>(&xp[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px]);
+                    const float2 b = *reinterpret_cast<const float2*>(&xp[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px + 2]);
+                    win[r][0] = a.x; win[r][1] = a.y; win[r][2] = b.x; win[r][3] = b.y;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const v4f wa = *reinterpret_cast<const v4f*>(&w1s[((ci * 3 + ky) * 3 + kx) * C1]);
+                        const v4f wb = *reinterpret_cast<const v4f*>(&w1s[((ci * 3 + ky) * 3 + kx) * C1 + 4]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const float v = win[i + ky][j + kx];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    acc[i * 2 + j][q] = __builtin_fmaf(wa[q], v, acc[i * 2 + j][q]);
+                                    acc[i * 2 + j][4 + q] = __builtin_fmaf(wb[q], v, acc[i * 2 + j][4 + q]);
+                                }
+                            }
+                    }
+            }
+#pragma unroll
+            for (int co = 0; co < C1; ++co) {
+                const float bb = w1s[CIN * 9 * C1 + co];
+                float best = fmaxf(acc[0][co] + bb, 0.0f);
+                int idx = 0;
+#pragma unroll
+                for (int p = 1; p < 4; ++p) {
+                    const float v = fmaxf(acc[p][co] + bb, 0.0f);
+                    if (v > best) { best = v; idx = p; }
+                }
+                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = best;
+                if (p1g) {
+                    p1g[((size_t)s * C1 + co) * PC + tid] = best;
+                    amax[((size_t)s * C1 + co) * PC + tid] = (uint8_t)idx;
+                }
+            }
+        }
+        __syncthreads();
+        if (own) {
+            // ---- conv2 + bias + ReLU
+            float acc2[C2];
+#pragma unroll
+            for (int co = 0; co < C2; ++co) acc2[co] = 0.0f;
+#pragma unroll 1
+            for (int ci = 0; ci < C1; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = pp[ci * PP_PLANE + (py + ky) * PP_RS + px + kx];
+                        const float* wrow = &w2s[((ci * 3 + ky) * 3 + kx) * C2];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const v4f w = *reinterpret_cast<const v4f*>(wrow + 4 * q4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc2[4 * q4 + q] = __builtin_fmaf(w[q], v, acc2[4 * q4 + q]);
+                        }
+                    }
+#pragma unroll
+            for (int co = 0; co < C2; ++co)
+                a2[(size_t)s * FLAT + co * PC + tid] = fmaxf(acc2[co] + w2s[C1 * 9 * C2 + co], 0.0f);
+        }
+        cnn_clear_onehots<CIN>(xp, loc, pc);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 backward: dL/d(a2) -> per-workgroup partial sums of dW1, db1, dW2, db2 (slab row layout:
+// [dW1 8*CIN*9 | db1 8 | dW2 16*72 | db2 16], torch weight order).
+template <int CIN>
+__global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ w2, const float* __restrict__ da2,
+                                                            const float* __restrict__ a2, const float* __restrict__ p1g,
+                                                            const uint8_t* __restrict__ amax, float* __restrict__ slab) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int K1 = CIN * 9;
+    float* xp = smem;                               // [CIN][28][28]
+    float* pp = xp + CIN * XP_PLANE;                // [8][15][15]   padded P1
+    float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
+    float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
+    float* w2b = gbuf + C1 * PC;                    // [(co,ky,kx)][8 ci]
+    uint8_t* ambuf = reinterpret_cast<uint8_t*>(w2b + C2 * 9 * C1);   // [8][169]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;
+    for (int e = tid; e < C2 * C1 * 9; e += CNN_NT) {           // torch [co][ci][ky][kx] -> [(co,ky,kx)][ci]
+        const int co = e / (C1 * 9), r = e - co * (C1 * 9);
+        const int ci = r / 9, kk = r - ci * 9;
+        w2b[(co * 9 + kk) * C1 + ci] = w2[e];
+    }
+    __syncthreads();
+    const int py = tid / PW, px = tid - py * PW;
+    const bool own = tid < PC;
+    // dW2 (+ db2 in column 72) accumulators: 5 column tiles of the [16 co] x [80] product, this wave's share of the pixels
+    v4f accw[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) accw[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // dW1 row of channel co1 (+ db1 in slot K1): this thread's share of the cells
+    float aw1[K1 + 1];
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) aw1[k] = 0.0f;
+    const int co1 = tid & 7, grp = tid >> 3;        // 24 groups of 8 channels
+    // MFMA operand coordinates of this lane
+    const int mrow = lane & 15, mk = lane >> 4;
+    int bci[5], bky[5], bkx[5], bmode[5];           // B column n = 16*tile + mrow -> (ci,ky,kx) / ones / zero
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int n = 16 * t + mrow;
+        bmode[t] = (n < 72) ? 0 : ((n == 72) ? 1 : 2);
+        const int nn = (n < 72) ? n : 0;
+        bci[t] = nn / 9; bky[t] = (nn % 9) / 3; bkx[t] = nn % 3;
+    }
+    for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
+        int loc, pc;
+        cnn_load_input<CIN>(in, s, xp, loc, pc);
+        if (own) {
+#pragma unroll
+            for (int co = 0; co < C1; ++co) {
+                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = p1g[((size_t)s * C1 + co) * PC + tid];
+                ambuf[co * PC + tid] = amax[((size_t)s * C1 + co) * PC + tid];
+            }
+#pragma unroll
+            for (int co = 0; co < C2; ++co) {
+                const size_t o = (size_t)s * FLAT + co * PC + tid;
+                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = (a2[o] > 0.0f) ? da2[o] : 0.0f;     // ReLU gate
+            }
+        }
+        __syncthreads();
+        // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
+        for (int st = wave; st < 43; st += 3) {
+            const int pxl = 4 * st + mk;
+            const bool ok = pxl < PC;
+            const int pq = ok ? pxl : (PC - 1);
+            const int y = pq / PW, x = pq - y * PW;
+            const float av = ok ? dzp[mrow * PP_PLANE + (y + 1) * PP_RS + x + 1] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                float bv = pp[bci[t] * PP_PLANE + (y + bky[t]) * PP_RS + x + bkx[t]];
+                bv = (bmode[t] == 0) ? bv : ((bmode[t] == 1) ? 1.0f : 0.0f);
+                accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accw[t], 0, 0, 0);
+            }
+        }
+        // ---- dP1 = conv2^T(dZ2), gated by the pool's ReLU (P1 > 0)
+        if (own) {
+            float g[C1];
+#pragma unroll
+            for (int ci = 0; ci < C1; ++ci) g[ci] = 0.0f;
+#pragma unroll 1
+            for (int co = 0; co < C2; ++co)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = dzp[co * PP_PLANE + (py + 2 - ky) * PP_RS + px + 2 - kx];
+                        const v4f wa = *reinterpret_cast<const v4f*>(&w2b[((co * 3 + ky) * 3 + kx) * C1]);
+                        const v4f wb = *reinterpret_cast<const v4f*>(&w2b[((co * 3 + ky) * 3 + kx) * C1 + 4]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            g[q] = __builtin_fmaf(wa[q], v, g[q]);
+                            g[4 + q] = __builtin_fmaf(wb[q], v, g[4 + q]);
+                        }
+                    }
+#pragma unroll
+            for (int ci = 0; ci < C1; ++ci)
+                gbuf[ci * PC + tid] = (pp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1] > 0.0f) ? g[ci] : 0.0f;
+        }
+        __syncthreads();
+        // ---- dW1[co1][:] += g[co1][cell] * x-window at the cell's arg-max pixel
+        for (int c = grp; c < PC; c += CNN_NT / 8) {
+            const float gv = gbuf[co1 * PC + c];
+            if (gv != 0.0f) {
+                const int am = ambuf[co1 * PC + c];
+                const int cy = c / PW, cx = c - cy * PW;
+                const float* base = xp + (2 * cy + (am >> 1)) * XP_RS + 2 * cx + (am & 1);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            aw1[(ci * 3 + ky) * 3 + kx] = __builtin_fmaf(gv, base[ci * XP_PLANE + ky * XP_RS + kx], aw1[(ci * 3 + ky) * 3 + kx]);
+                aw1[K1] += gv;
+            }
+        }
+        __syncthreads();
+        cnn_clear_onehots<CIN>(xp, loc, pc);
+        __syncthreads();
+    }
+    // ---- workgroup reduction (fixed order) -> slab row
+    // (the 8 lanes of a wave that share co1 are first summed with a fixed xor tree)
+    __syncthreads();
+    float* red = smem;                               // aliases the image buffers: [3 waves][8][K1+1] then [3][16][80]
+    float* red2 = red + 3 * C1 * (K1 + 1);
+#pragma unroll
+    for (int k = 0; k <= K1; ++k) {
+        float v = aw1[k];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < C1) red[(wave * C1 + lane) * (K1 + 1) + k] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red2[(wave * 16 + 4 * mk + j) * 80 + 16 * t + mrow] = accw[t][j];
+    __syncthreads();
+    constexpr int ROW = C1 * K1 + C1 + C2 * 72 + C2;
+    float* out = slab + (size_t)blockIdx.x * ROW;
+    for (int e = tid; e < C1 * (K1 + 1); e += CNN_NT) {
+        const int c = e / (K1 + 1), k = e - c * (K1 + 1);
+        const float sum = red[(0 * C1 + c) * (K1 + 1) + k] + red[(1 * C1 + c) * (K1 + 1) + k] + red[(2 * C1 + c) * (K1 + 1) + k];
+        if (k < K1) out[c * K1 + k] = sum; else out[C1 * K1 + c] = sum;
+    }
+    for (int e = tid; e < C2 * 73; e += CNN_NT) {
+        const int co = e / 73, n = e - co * 73;
+        const float sum = red2[(0 * 16 + co) * 80 + n] + red2[(1 * 16 + co) * 80 + n] + red2[(2 * 16 + co) * 80 + n];
+        if (n < 72) out[C1 * K1 + C1 + co * 72 + n] = sum; else out[C1 * K1 + C1 + C2 * 72 + co] = sum;
+    }
+}
+
+inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE + (cin * 9 + 1) * C1 + (C1 * 9 + 1) * C2); }
+inline size_t bwd_lds(int cin) {
+    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC + C2 * 9 * C1) * 4 + C1 * PC;
+    size_t red = (size_t)(3 * C1 * (cin * 9 + 1) + 3 * 16 * 80) * 4;
+    return ((img > red ? img : red) + 15) & ~(size_t)15;
+}
+inline int cnn_grid(long long S, int per_cu) {      // persistent: as many workgroups as fit per CU, each strides over the batch
+    const long long cap = 256 * per_cu;
+    return (int)(S < cap ? S : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rs_cnn_trunk_slab_row(int32_t in_channels) { return C1 * in_channels * 9 + C1 + C2 * 72 + C2; }
+int32_t rs_cnn_trunk_slab_rows(int64_t num_samples) { return cnn_grid(num_samples, 3); }
+
+int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
+                         int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
+                         float* p1, uint8_t* amax, rs_stream_t stream) {
+    if (!maps || !w1 || !b1 || !w2 || !b2 || !a2 || num_samples < 0 || ((p1 == nullptr) != (amax == nullptr))) return RS_ERR_INVALID_ARG;
+    if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
+    if (num_samples == 0) return RS_OK;
+    CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = cnn_grid(num_samples, 4);
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(grid), dim3(CNN_NT), fwd_lds(6), s, in, w1, b1, w2, b2, a2, p1, amax);
+    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(grid), dim3(CNN_NT), fwd_lds(4), s, in, w1, b1, w2, b2, a2, p1, amax);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
+                          int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
+                          const uint8_t* amax, float* slab, rs_stream_t stream) {
+    if (!maps || !w2 || !da2 || !a2 || !p1 || !amax || !slab || num_samples <= 0) return RS_ERR_INVALID_ARG;
+    if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
+    CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = cnn_grid(num_samples, 3);
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(grid), dim3(CNN_NT), bwd_lds(6), s, in, w2, da2, a2, p1, amax, slab);
+    else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(grid), dim3(CNN_NT), bwd_lds(4), s, in, w2, da2, a2, p1, amax, slab);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+}  // extern "C"

@@ -95,6 +95,62 @@ class HeatMaps:
                    "rs_maps_stack")
         return self.actor_stack, self.critic_stack
 
+    def shared_maps(self) -> torch.Tensor:
+        """The 4 maps every owner shares, [N,4,X,Y] = {combined, readings, visits, obstacles} (= the critic stack);
+        the per-owner actor stacks are formed inside the CNN trunk kernel from these + the owners' cells."""
+        _lib.check(self.lib.rs_maps_stack(self._h, None, self.critic_stack.data_ptr(), self.env._stream()), "rs_maps_stack")
+        return self.critic_stack
+
+
+class ConvTrunk(torch.autograd.Function):
+    """conv-ReLU-maxpool-conv-ReLU-flatten of the RAD-TEAM CNNs (RADTEAM_core.py:962-1023, :1211-1271) on the HIP
+    kernels rs_cnn_trunk_forward / rs_cnn_trunk_backward, fed by the resident shared maps (no stack in HBM).
+    agent >= 0: the owner's 6-channel actor input; agent < 0: the 4-channel critic input."""
+
+    @staticmethod
+    def forward(ctx, maps, cells, pcells, agent, w1, b1, w2, b2):
+        lib = _lib.load()
+        S = maps.shape[0]
+        assert maps.dtype == torch.float32 and maps.is_contiguous() and maps[0].numel() == 4 * 729
+        A = 0
+        if agent >= 0:
+            assert cells.dtype == torch.int64 and pcells.dtype == torch.int64 and cells.is_contiguous() and pcells.is_contiguous()
+            assert cells.shape == pcells.shape and cells.shape[0] == S
+            A = cells.shape[1]
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        assert w1c.shape == (8, 6 if agent >= 0 else 4, 3, 3) and w2c.shape == (16, 8, 3, 3)
+        train = any(ctx.needs_input_grad[4:8])
+        a2 = torch.empty(S, 2704, dtype=torch.float32, device=maps.device)
+        p1 = torch.empty(S, 8, 169, dtype=torch.float32, device=maps.device) if train else None
+        amax = torch.empty(S, 8, 169, dtype=torch.uint8, device=maps.device) if train else None
+        stream = torch.cuda.current_stream(maps.device).cuda_stream
+        _lib.check(lib.rs_cnn_trunk_forward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
+                                            pcells.data_ptr() if agent >= 0 else None, A, agent, S, w1c.data_ptr(), b1c.data_ptr(),
+                                            w2c.data_ptr(), b2c.data_ptr(), a2.data_ptr(), p1.data_ptr() if train else None,
+                                            amax.data_ptr() if train else None, stream), "rs_cnn_trunk_forward")
+        if train:
+            ctx.save_for_backward(maps, cells if agent >= 0 else maps, pcells if agent >= 0 else maps, w2c, a2, p1, amax)
+            ctx.agent, ctx.A, ctx.cin = agent, A, (6 if agent >= 0 else 4)
+        return a2
+
+    @staticmethod
+    def backward(ctx, da2):
+        lib = _lib.load()
+        maps, cells, pcells, w2c, a2, p1, amax = ctx.saved_tensors
+        S, cin, agent = maps.shape[0], ctx.cin, ctx.agent
+        da2 = da2.contiguous()
+        rows, row = lib.rs_cnn_trunk_slab_rows(S), lib.rs_cnn_trunk_slab_row(cin)
+        slab = torch.empty(rows, row, dtype=torch.float32, device=maps.device)
+        stream = torch.cuda.current_stream(maps.device).cuda_stream
+        _lib.check(lib.rs_cnn_trunk_backward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
+                                             pcells.data_ptr() if agent >= 0 else None, ctx.A, agent, S, w2c.data_ptr(),
+                                             da2.data_ptr(), a2.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(), stream),
+                   "rs_cnn_trunk_backward")
+        g = slab.sum(dim=0)
+        n1 = 8 * cin * 9
+        return (None, None, None, None, g[:n1].view(8, cin, 3, 3), g[n1:n1 + 8], g[n1 + 8:n1 + 8 + 1152].view(16, 8, 3, 3),
+                g[n1 + 8 + 1152:])
+
 
 class CNNActor(nn.Module):
     """RADTEAM_core.Actor (:935-1180): conv3x3(6->8)-ReLU-maxpool2-conv3x3(8->16)-ReLU-flatten-32-16-8 softmax."""
@@ -109,7 +165,18 @@ class CNNActor(nn.Module):
             nn.Softmax(dim=-1))
 
     def logits(self, x):
+        """Dense [B,6,X,Y] input through the nn.Sequential (library convolutions): the plain-PyTorch reference of
+        logits_from_maps, used by tests."""
         for layer in list(self.actor)[:-1]:
+            x = layer(x)
+        return x
+
+    def logits_from_maps(self, maps, cells, pcells, agent: int):
+        """Owner `agent`'s logits for samples described by the resident shared maps [S,4,X,Y] + cell indices [S,A]:
+        HIP trunk (ConvTrunk) + the three Linear layers."""
+        a = self.actor
+        x = ConvTrunk.apply(maps, cells, pcells, agent, a[0].weight, a[0].bias, a[3].weight, a[3].bias)
+        for layer in list(a)[6:-1]:
             x = layer(x)
         return x
 
@@ -129,4 +196,13 @@ class CNNCritic(nn.Module):
             nn.Linear(16 * pool_output * pool_output, 32), nn.ReLU(), nn.Linear(32, 16), nn.ReLU(), nn.Linear(16, 1))
 
     def forward(self, x):
+        """Dense [B,4,X,Y] input through the nn.Sequential (library convolutions): the plain-PyTorch reference."""
         return self.critic(x).squeeze(-1)
+
+    def value_from_maps(self, maps):
+        """V for samples given as resident shared maps [S,4,X,Y]: HIP trunk (ConvTrunk) + the Linear layers."""
+        c = self.critic
+        x = ConvTrunk.apply(maps, None, None, -1, c[0].weight, c[0].bias, c[3].weight, c[3].bias)
+        for layer in list(c)[6:]:
+            x = layer(x)
+        return x.squeeze(-1)

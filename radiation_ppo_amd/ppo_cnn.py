@@ -64,16 +64,26 @@ class CNNAgentPPO:
                     p.data.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
 
+    def _logits(self, x):
+        """x: dense [B,6,X,Y] stack (library convolutions; tests) or (maps, cells, pcells, agent) -> HIP trunk."""
+        return self.pi.logits_from_maps(*x) if isinstance(x, tuple) else self.pi.logits(x)
+
+    def _values(self, x):
+        """x: dense [B,4,X,Y] stack or (maps,) resident shared maps -> HIP trunk."""
+        return self.critic.value_from_maps(*x) if isinstance(x, tuple) else self.critic(x)
+
     @torch.no_grad()
-    def act(self, actor_stack: torch.Tensor, critic_stack: torch.Tensor, u: torch.Tensor):
-        logp_all = torch.log_softmax(self.pi.logits(actor_stack), dim=-1)
+    def act(self, actor_in, u: torch.Tensor):
+        """select_action (RADTEAM_core.py:1838-1892): inverse-CDF sample from the actor's distribution."""
+        logp_all = torch.log_softmax(self._logits(actor_in), dim=-1)
         cdf = torch.cumsum(logp_all.exp(), dim=-1)
         a = (cdf <= u.unsqueeze(-1)).sum(dim=-1).clamp_(max=logp_all.shape[-1] - 1)
         logp = logp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1)
-        return a, logp, self.critic(critic_stack)
+        return a, logp
 
     def update_agent(self, actor_in, critic_in, act, adv, ret, logp_old, w, update_critic: bool) -> UpdateResult:
-        """actor_in(lo, hi) / critic_in(lo, hi) return the map stacks of samples [lo, hi); w sums to 1 over the global batch."""
+        """actor_in(lo, hi) / critic_in(lo, hi) describe the inputs of samples [lo, hi) (see _logits / _values);
+        w sums to 1 over the global batch."""
         M = act.shape[0]
         thr = 1.5 * self.target_kl
         kk, kl_reached, last = 0, False, None
@@ -82,7 +92,7 @@ class CNNAgentPPO:
             stats = torch.zeros(4, dtype=torch.float64, device=self.device)
             for lo in range(0, M, self.chunk):
                 hi = min(lo + self.chunk, M)
-                logp_all = torch.log_softmax(self.pi.logits(actor_in(lo, hi)), dim=-1)
+                logp_all = torch.log_softmax(self._logits(actor_in(lo, hi)), dim=-1)
                 logp = logp_all.gather(-1, act[lo:hi].unsqueeze(-1)).squeeze(-1)
                 ratio = torch.exp(logp - logp_old[lo:hi])
                 clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv[lo:hi]
@@ -110,7 +120,7 @@ class CNNAgentPPO:
                 tot = torch.zeros((), dtype=torch.float64, device=self.device)
                 for lo in range(0, M, self.chunk):
                     hi = min(lo + self.chunk, M)
-                    v = self.critic(critic_in(lo, hi))
+                    v = self._values(critic_in(lo, hi))
                     lc = (w[lo:hi] * (v - ret[lo:hi]) ** 2).sum()               # MSE (ppo.py:1040-1045)
                     lc.backward()
                     tot += lc.detach().double()
@@ -166,11 +176,11 @@ class CNNCollector:
         return torch.cat([pm.view(B, 1, X, Y), loc, shared[:, 0:1] - loc, shared[:, 1:4]], dim=1)
 
     @torch.no_grad()
-    def _policy(self, t: Optional[int]):
-        """One select_action round for every agent (maps updated once per round, as every owner's MapsBuffer is)."""
-        self.maps.update(self.obs)
-        actor, critic = self.maps.stacks()
-        return actor, critic
+    def _round(self, mask: Optional[torch.Tensor] = None):
+        """One select_action round of every owner's MapsBuffer (maps updated once, shared by all owners): returns
+        the resident shared maps [N,4,X,Y] and the owners' location / prediction cells [N,A]."""
+        self.maps.update(self.obs, mask=mask)
+        return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
 
     @torch.no_grad()
     def collect(self) -> Dict[str, torch.Tensor]:
@@ -185,16 +195,19 @@ class CNNCollector:
         ep_cnt = torch.zeros((), dtype=torch.float64, device=dev)
         self.complete_len.zero_()
         for t in range(T):
-            actor, critic = self._policy(t)
+            critic, cells, pcells = self._round()
             self.shared[t] = critic
-            self.cells[t] = self.maps.field("cell").long()
-            self.pcells[t] = self.maps.field("pred_cell").long()
+            self.cells[t] = cells
+            self.pcells[t] = pcells
             env.action_uniforms(self._u)
+            v_shared = None
             for a, ag in self.agents.items():
-                act, logp, v = ag.act(actor[:, a], critic, self._u[:, a])
+                act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
+                if not ag.global_critic or v_shared is None:      # one evaluation serves every owner of a global critic
+                    v_shared = ag._values((critic,))
                 buf.act[t, :, a] = act
                 buf.logp[t, :, a] = logp
-                buf.val[t, :, a] = v
+                buf.val[t, :, a] = v_shared
                 self._act8[:, a] = act.to(torch.int8)
             buf.obs[t] = self.obs
             next_obs, rew, team, done, info = env.step(self._act8)
@@ -214,10 +227,11 @@ class CNNCollector:
             self.obs = next_obs.clone()
             # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480);
             # the maps of those envs see the final observation a second time, exactly as in the reference
-            self.maps.update(self.obs, mask=boot & cut)
-            actor_b, critic_b = self.maps.stacks()
+            critic_b, _, _ = self._round(mask=boot & cut)
+            vb = None
             for a, ag in self.agents.items():
-                vb = ag.critic(critic_b)
+                if not ag.global_critic or vb is None:
+                    vb = ag._values((critic_b,))
                 buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
             ep_ret_sum += (self.ep_ret[:, 0].double() * episode_over).sum()
             ep_len_sum += (self.steps_in_ep.double() * episode_over).sum()
@@ -248,8 +262,8 @@ class CNNCollector:
         out = {}
         for a, ag in self.agents.items():
             adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
-            actor_in = lambda lo, hi, a=a: self.actor_stack_from(shared[lo:hi], cells[lo:hi], pcells[lo:hi], a)
-            critic_in = lambda lo, hi: shared[lo:hi]
+            actor_in = lambda lo, hi, a=a: (shared[lo:hi], cells[lo:hi], pcells[lo:hi], a)
+            critic_in = lambda lo, hi: (shared[lo:hi],)
             upd_c = (not ag.global_critic) or a == 0
             out[a] = ag.update_agent(actor_in, critic_in, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
                                      buf.logp[:, :, a].reshape(-1), w, update_critic=upd_c)

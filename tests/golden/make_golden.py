@@ -645,8 +645,23 @@ def gen_cnn_loss():
     critic = R.Critic(map_dim=(27, 27))
     rng = np.random.default_rng(19)
     n = 14
-    xa = (rng.random((n, 1, 6, 27, 27)) * (rng.random((n, 1, 6, 27, 27)) < 0.05)).astype(np.float32)
-    xc = (rng.random((n, 1, 4, 27, 27)) * (rng.random((n, 1, 4, 27, 27)) < 0.05)).astype(np.float32)
+    # inputs in the form the trainer holds them: the 4 shared maps + the owner's location / prediction cells; the
+    # actor stack follows CNNBase.get_map_stack (RADTEAM_core.py:1791-1836): {prediction, location, others =
+    # combined - location, readings, visits, obstacles}
+    maps = (rng.random((n, 4, 27, 27)) * (rng.random((n, 4, 27, 27)) < 0.08)).astype(np.float32)
+    cells = rng.integers(0, 729, size=n)
+    pcells = np.where(rng.random(n) < 0.7, rng.integers(0, 729, size=n), -1)
+    for i in range(n):
+        maps[i, 0] = np.round(maps[i, 0] * 3)                       # combined-locations map holds small counts
+        maps[i, 0].reshape(-1)[cells[i]] += 1.0
+    xa = np.zeros((n, 1, 6, 27, 27), dtype=np.float32)
+    for i in range(n):
+        if pcells[i] >= 0:
+            xa[i, 0, 0].reshape(-1)[pcells[i]] = 1.0
+        xa[i, 0, 1].reshape(-1)[cells[i]] = 1.0
+        xa[i, 0, 2] = maps[i, 0] - xa[i, 0, 1]
+        xa[i, 0, 3:6] = maps[i, 1:4]
+    xc = maps[:, None].copy()
     act = torch.from_numpy(rng.integers(0, 8, size=n))
     adv = torch.from_numpy(rng.normal(size=n).astype(np.float32))
     ret = torch.from_numpy(rng.normal(size=n).astype(np.float32))
@@ -663,7 +678,7 @@ def gen_cnn_loss():
     pi["pi_loss"].backward()
     cr = RP.AgentPPO.compute_batched_losses_critic(me, data=data, map_buffer_maps=[torch.from_numpy(x) for x in xc], sample=sample)
     cr["critic_loss"].backward()
-    out = dict(xa=xa, xc=xc, act=act.numpy(), adv=adv.numpy(), ret=ret.numpy(), logp_old=logp_old.numpy(),
+    out = dict(xa=xa, xc=xc, maps=maps, cells=cells.astype(np.int64), pcells=pcells.astype(np.int64), act=act.numpy(), adv=adv.numpy(), ret=ret.numpy(), logp_old=logp_old.numpy(),
                pi_loss=np.float32(pi["pi_loss"].item()), kl=np.float64(pi["kl"]), entropy=np.float64(pi["entropy"]),
                clip_fraction=np.float64(pi["clip_fraction"]), critic_loss=np.float32(cr["critic_loss"].item()))
     # (the reference modules also carry unused debugging copies `step1..step7` of the layers: not saved)
