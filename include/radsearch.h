@@ -264,16 +264,18 @@ int rs_maps_field(rs_maps* m, const char* name, void** dev_ptr, int32_t* elem_by
  *   w1 [8][Cin][3][3], b1 [8], w2 [16][8][3][3], b2 [16]: torch Conv2d layouts
  *   a2 [S][2704] (= Flatten of the ReLU'd conv2 output); p1 [S][8][169] and amax [S][8][169] (pooled activations and
  *   the winning pixel of each 2x2 window) are written when non-NULL (both or neither) and are what backward consumes.
- * Backward: da2 [S][2704] = dL/d(a2); slab [rs_cnn_trunk_slab_rows(S)][rs_cnn_trunk_slab_row(Cin)] receives
- * per-workgroup partial sums laid out {dW1 8*Cin*9 | db1 8 | dW2 1152 | db2 16}; the caller sums the rows. */
+ * Backward: da2 [S][2704] = dL/d(a2); slab [rs_cnn_trunk_slab_rows(S, Cin)][rs_cnn_trunk_slab_row(Cin)] receives
+ * per-workgroup partial sums laid out {dW1 8*Cin*9 | db1 8 | dW2 1152 | db2 16}; the caller sums the rows.
+ * wscratch: device scratch of rs_cnn_trunk_scratch_floats(Cin) floats (the weights re-laid-out for scalar loads). */
 int32_t rs_cnn_trunk_slab_row(int32_t in_channels);
-int32_t rs_cnn_trunk_slab_rows(int64_t num_samples);
+int32_t rs_cnn_trunk_slab_rows(int64_t num_samples, int32_t in_channels);
+int32_t rs_cnn_trunk_scratch_floats(int32_t in_channels);
 int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                          int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
-                         float* p1, uint8_t* amax, rs_stream_t stream);
+                         float* p1, uint8_t* amax, float* wscratch, rs_stream_t stream);
 int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                           int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
-                          const uint8_t* amax, float* slab, rs_stream_t stream);
+                          const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,12 @@
 
 namespace {
 
+#ifndef CNN_BWD_WAVES
+#define CNN_BWD_WAVES 2
+#endif
+#ifndef CNN_BWD_PREFETCH
+#define CNN_BWD_PREFETCH 1
+#endif
 constexpr int CNN_NT = 192;                 // threads per workgroup (3 waves); 169 of them own a pooled cell / pixel
 constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
 constexpr int PW = 13, PC = 169;            // pooled side and cells
@@ -35,6 +41,36 @@ constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded 
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+// Weights are read through the scalar unit: a wave-uniform s_load_dwordx8/x16 from the constant address space feeds
+// v_fma's SGPR operand, so they cost neither LDS return bandwidth nor VGPRs.  (Broadcast ds_reads still return
+// 64 x 16 B per wave and made conv2 / dP1 LDS-bound.)  The scalar loads want [tap][channel] rows, produced once per
+// call by rs_cnn_prep_kernel into a caller-provided scratch:
+//   [w1t (Cin*9) x 8 | b1 8 | w2t 72 x 16 | b2 16 | w2b (co,ky,kx)=144 x 8 ci]
+typedef const float __attribute__((address_space(4))) * cmem_t;
+__device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
+constexpr int WT_W1(int) { return 0; }
+constexpr int WT_B1(int cin) { return cin * 9 * 8; }
+constexpr int WT_W2(int cin) { return cin * 9 * 8 + 8; }
+constexpr int WT_B2(int cin) { return cin * 9 * 8 + 8 + 72 * 16; }
+constexpr int WT_W2B(int cin) { return cin * 9 * 8 + 8 + 72 * 16 + 16; }
+constexpr int WT_TOTAL(int cin) { return cin * 9 * 8 + 8 + 72 * 16 + 16 + 144 * 8; }
+
+__global__ void rs_cnn_prep_kernel(int cin, const float* __restrict__ w1, const float* __restrict__ b1,
+                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ wt) {
+    const int K1 = cin * 9;
+    for (int e = threadIdx.x; w1 && e < 8 * K1; e += blockDim.x) {       // torch [co][ci][ky][kx] -> [(ci,ky,kx)][co]
+        const int co = e / K1, k = e - co * K1;
+        wt[WT_W1(cin) + k * 8 + co] = w1[e];
+    }
+    for (int e = threadIdx.x; e < 16 * 72; e += blockDim.x) {
+        const int co = e / 72, k = e - co * 72;
+        wt[WT_W2(cin) + k * 16 + co] = w2[e];                             // [(ci,ky,kx)][co]
+        const int ci = k / 9, kk = k - ci * 9;
+        wt[WT_W2B(cin) + (co * 9 + kk) * 8 + ci] = w2[e];                 // [(co,ky,kx)][ci]
+    }
+    if (threadIdx.x < 8) wt[WT_B1(cin) + threadIdx.x] = b1 ? b1[threadIdx.x] : 0.0f;
+    if (threadIdx.x < 16) wt[WT_B2(cin) + threadIdx.x] = b2 ? b2[threadIdx.x] : 0.0f;
+}
 
 struct CnnIn {
     const float* maps;        // [S][4][729]: combined, readings, visits, obstacles
@@ -44,22 +80,46 @@ struct CnnIn {
     long long S;
 };
 
-// ---- stage one sample's input planes in LDS; returns the one-hot cells the caller must clear afterwards
+// ---- one sample's inputs travel HBM -> registers -> LDS; the registers of sample s+grid are filled while sample s
+// is being computed (software prefetch), so the per-image memory latency is off the critical path
+constexpr int MAPS_PER_THREAD = (4 * MAPC + CNN_NT - 1) / CNN_NT;     // 16
+struct CnnFetch {
+    float m[MAPS_PER_THREAD];
+    int loc, pc;
+};
+
 template <int CIN>
-__device__ __forceinline__ void cnn_load_input(const CnnIn& in, long long s, float* xp, int& loc, int& pc) {
+__device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch& f) {
     const float* src = in.maps + (size_t)s * 4 * MAPC;
-    constexpr int CH0 = (CIN == 6) ? 2 : 0;
-    for (int e = threadIdx.x; e < 4 * MAPC; e += CNN_NT) {
-        const int m = e / MAPC, q = e - m * MAPC;
-        const int r = q / MAPW, c = q - r * MAPW;
-        xp[(CH0 + m) * XP_PLANE + (r + 1) * XP_RS + (c + 1)] = src[e];
+#pragma unroll
+    for (int i = 0; i < MAPS_PER_THREAD; ++i) {
+        const int e = threadIdx.x + i * CNN_NT;
+        f.m[i] = (e < 4 * MAPC) ? src[e] : 0.0f;
     }
-    loc = -1; pc = -1;
+    f.loc = -1; f.pc = -1;
     if (CIN == 6) {
-        loc = (int)in.cells[(size_t)s * in.A + in.agent];
-        pc = (int)in.pcells[(size_t)s * in.A + in.agent];
+        f.loc = (int)in.cells[(size_t)s * in.A + in.agent];
+        f.pc = (int)in.pcells[(size_t)s * in.A + in.agent];
     }
-    __syncthreads();
+}
+
+template <int CIN>
+__device__ __forceinline__ void cnn_stage(const CnnFetch& f, float* xp) {
+    constexpr int CH0 = (CIN == 6) ? 2 : 0;
+#pragma unroll
+    for (int i = 0; i < MAPS_PER_THREAD; ++i) {
+        const int e = threadIdx.x + i * CNN_NT;
+        if (e < 4 * MAPC) {
+            const int m = e / MAPC, q = e - m * MAPC;
+            const int r = q / MAPW, c = q - r * MAPW;
+            xp[(CH0 + m) * XP_PLANE + (r + 1) * XP_RS + (c + 1)] = f.m[i];
+        }
+    }
+}
+
+// the owner's one-hots (after the planes are in place)
+template <int CIN>
+__device__ __forceinline__ void cnn_set_onehots(float* xp, int loc, int pc) {
     if (CIN == 6 && threadIdx.x == 0) {
         const int lr = loc / MAPW, lc = loc - lr * MAPW;
         xp[1 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] = 1.0f;          // location map
@@ -69,7 +129,6 @@ __device__ __forceinline__ void cnn_load_input(const CnnIn& in, long long s, flo
             xp[0 * XP_PLANE + (pr + 1) * XP_RS + pcc + 1] = 1.0f;      // prediction map
         }
     }
-    __syncthreads();
 }
 
 template <int CIN>
@@ -89,33 +148,27 @@ __device__ __forceinline__ void cnn_clear_onehots(float* xp, int loc, int pc) {
 // training p1 [S][8][169] (pooled activations) + amax [S][8][169] (which pixel of the 2x2 window won, 0..3 in
 // row-major order; first maximum wins like torch's CPU max_pool2d).
 template <int CIN>
-__global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                                            float* __restrict__ a2, float* __restrict__ p1g,
-                                                            uint8_t* __restrict__ amax) {
+__global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
+                                                            float* __restrict__ p1g, uint8_t* __restrict__ amax) {
     extern __shared__ __align__(16) float smem[];
     float* xp = smem;                               // [CIN][28][28]
     float* pp = xp + CIN * XP_PLANE;                // [8][15][15]
-    float* w1s = pp + C1 * PP_PLANE;                // [(ci,ky,kx)][8] + b1[8]
-    float* w2s = w1s + (CIN * 9 + 1) * C1;          // [(ci,ky,kx)][16] + b2[16]
+    const cmem_t w1c = as_cmem(wt + WT_W1(CIN)), b1c = as_cmem(wt + WT_B1(CIN));
+    const cmem_t w2c = as_cmem(wt + WT_W2(CIN)), b2c = as_cmem(wt + WT_B2(CIN));
     const int tid = threadIdx.x;
     for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;     // borders stay zero
-    for (int e = tid; e < CIN * 9 * C1; e += CNN_NT) {           // torch [co][ci][ky][kx] -> [(ci,ky,kx)][co]
-        const int co = e / (CIN * 9), k = e - co * (CIN * 9);
-        w1s[k * C1 + co] = w1[e];
-    }
-    if (tid < C1) w1s[CIN * 9 * C1 + tid] = b1[tid];
-    for (int e = tid; e < C2 * C1 * 9; e += CNN_NT) {
-        const int co = e / (C1 * 9), k = e - co * (C1 * 9);
-        w2s[k * C2 + co] = w2[e];
-    }
-    if (tid < C2) w2s[C1 * 9 * C2 + tid] = b2[tid];
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
+    CnnFetch f;
+    if ((long long)blockIdx.x < in.S) cnn_fetch<CIN>(in, blockIdx.x, f);
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
-        int loc, pc;
-        cnn_load_input<CIN>(in, s, xp, loc, pc);
+        const int loc = f.loc, pc = f.pc;
+        cnn_stage<CIN>(f, xp);
+        __syncthreads();
+        cnn_set_onehots<CIN>(xp, loc, pc);
+        if (s + gridDim.x < in.S) cnn_fetch<CIN>(in, s + gridDim.x, f);      // next sample: in flight during the compute
+        __syncthreads();
         if (own) {
             // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
             float acc[4][C1];
@@ -136,8 +189,12 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const v4f wa = *reinterpret_cast<const v4f*>(&w1s[((ci * 3 + ky) * 3 + kx) * C1]);
-                        const v4f wb = *reinterpret_cast<const v4f*>(&w1s[((ci * 3 + ky) * 3 + kx) * C1 + 4]);
+                        float wa[4], wb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            wa[q] = w1c[((ci * 3 + ky) * 3 + kx) * C1 + q];
+                            wb[q] = w1c[((ci * 3 + ky) * 3 + kx) * C1 + 4 + q];
+                        }
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -153,7 +210,7 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
             }
 #pragma unroll
             for (int co = 0; co < C1; ++co) {
-                const float bb = w1s[CIN * 9 * C1 + co];
+                const float bb = b1c[co];
                 float best = fmaxf(acc[0][co] + bb, 0.0f);
                 int idx = 0;
 #pragma unroll
@@ -181,17 +238,12 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float v = pp[ci * PP_PLANE + (py + ky) * PP_RS + px + kx];
-                        const float* wrow = &w2s[((ci * 3 + ky) * 3 + kx) * C2];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const v4f w = *reinterpret_cast<const v4f*>(wrow + 4 * q4);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc2[4 * q4 + q] = __builtin_fmaf(w[q], v, acc2[4 * q4 + q]);
-                        }
+                        for (int q = 0; q < C2; ++q) acc2[q] = __builtin_fmaf(w2c[((ci * 3 + ky) * 3 + kx) * C2 + q], v, acc2[q]);
                     }
 #pragma unroll
             for (int co = 0; co < C2; ++co)
-                a2[(size_t)s * FLAT + co * PC + tid] = fmaxf(acc2[co] + w2s[C1 * 9 * C2 + co], 0.0f);
+                a2[(size_t)s * FLAT + co * PC + tid] = fmaxf(acc2[co] + b2c[co], 0.0f);
         }
         cnn_clear_onehots<CIN>(xp, loc, pc);
         __syncthreads();
@@ -202,7 +254,7 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
 // K10 backward: dL/d(a2) -> per-workgroup partial sums of dW1, db1, dW2, db2 (slab row layout:
 // [dW1 8*CIN*9 | db1 8 | dW2 16*72 | db2 16], torch weight order).
 template <int CIN>
-__global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ w2, const float* __restrict__ da2,
+__global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ wt, const float* __restrict__ da2,
                                                             const float* __restrict__ a2, const float* __restrict__ p1g,
                                                             const uint8_t* __restrict__ amax, float* __restrict__ slab) {
     extern __shared__ __align__(16) float smem[];
@@ -211,15 +263,10 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
     float* pp = xp + CIN * XP_PLANE;                // [8][15][15]   padded P1
     float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
     float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
-    float* w2b = gbuf + C1 * PC;                    // [(co,ky,kx)][8 ci]
-    uint8_t* ambuf = reinterpret_cast<uint8_t*>(w2b + C2 * 9 * C1);   // [8][169]
+    uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [8][169]
+    const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;
-    for (int e = tid; e < C2 * C1 * 9; e += CNN_NT) {           // torch [co][ci][ky][kx] -> [(co,ky,kx)][ci]
-        const int co = e / (C1 * 9), r = e - co * (C1 * 9);
-        const int ci = r / 9, kk = r - ci * 9;
-        w2b[(co * 9 + kk) * C1 + ci] = w2[e];
-    }
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
@@ -242,23 +289,45 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
         const int nn = (n < 72) ? n : 0;
         bci[t] = nn / 9; bky[t] = (nn % 9) / 3; bkx[t] = nn % 3;
     }
-    for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
-        int loc, pc;
-        cnn_load_input<CIN>(in, s, xp, loc, pc);
+    CnnFetch f;
+    float fp1[C1], fa2[C2], fda2[C2];
+    uint8_t fam[C1];
+    auto fetch_acts = [&](long long s) {
         if (own) {
 #pragma unroll
             for (int co = 0; co < C1; ++co) {
-                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = p1g[((size_t)s * C1 + co) * PC + tid];
-                ambuf[co * PC + tid] = amax[((size_t)s * C1 + co) * PC + tid];
+                fp1[co] = p1g[((size_t)s * C1 + co) * PC + tid];
+                fam[co] = amax[((size_t)s * C1 + co) * PC + tid];
             }
 #pragma unroll
             for (int co = 0; co < C2; ++co) {
                 const size_t o = (size_t)s * FLAT + co * PC + tid;
-                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = (a2[o] > 0.0f) ? da2[o] : 0.0f;     // ReLU gate
+                fa2[co] = a2[o];
+                fda2[co] = da2[o];
             }
         }
+    };
+    if ((long long)blockIdx.x < in.S) { cnn_fetch<CIN>(in, blockIdx.x, f); if (CNN_BWD_PREFETCH) fetch_acts(blockIdx.x); }
+    for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
+        const int loc = f.loc, pc = f.pc;
+        if (!CNN_BWD_PREFETCH) fetch_acts(s);
+        cnn_stage<CIN>(f, xp);
+        if (own) {
+#pragma unroll
+            for (int co = 0; co < C1; ++co) {
+                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1[co];
+                ambuf[co * PC + tid] = fam[co];
+            }
+#pragma unroll
+            for (int co = 0; co < C2; ++co)
+                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = (fa2[co] > 0.0f) ? fda2[co] : 0.0f;     // ReLU gate
+        }
+        __syncthreads();
+        cnn_set_onehots<CIN>(xp, loc, pc);
+        if (s + gridDim.x < in.S) { cnn_fetch<CIN>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
         __syncthreads();
         // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
+#if !(defined(CNN_ABL) && CNN_ABL == 3)
         for (int st = wave; st < 43; st += 3) {
             const int pxl = 4 * st + mk;
             const bool ok = pxl < PC;
@@ -272,8 +341,14 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
                 accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accw[t], 0, 0, 0);
             }
         }
+#endif
         // ---- dP1 = conv2^T(dZ2), gated by the pool's ReLU (P1 > 0)
+#if defined(CNN_ABL) && CNN_ABL == 2
+        if (own) for (int ci = 0; ci < C1; ++ci) gbuf[ci * PC + tid] = dzp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1];
+        if (false) {
+#else
         if (own) {
+#endif
             float g[C1];
 #pragma unroll
             for (int ci = 0; ci < C1; ++ci) g[ci] = 0.0f;
@@ -284,13 +359,8 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float v = dzp[co * PP_PLANE + (py + 2 - ky) * PP_RS + px + 2 - kx];
-                        const v4f wa = *reinterpret_cast<const v4f*>(&w2b[((co * 3 + ky) * 3 + kx) * C1]);
-                        const v4f wb = *reinterpret_cast<const v4f*>(&w2b[((co * 3 + ky) * 3 + kx) * C1 + 4]);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            g[q] = __builtin_fmaf(wa[q], v, g[q]);
-                            g[4 + q] = __builtin_fmaf(wb[q], v, g[4 + q]);
-                        }
+                        for (int q = 0; q < C1; ++q) g[q] = __builtin_fmaf(w2b[((co * 3 + ky) * 3 + kx) * C1 + q], v, g[q]);
                     }
 #pragma unroll
             for (int ci = 0; ci < C1; ++ci)
@@ -298,7 +368,11 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
         }
         __syncthreads();
         // ---- dW1[co1][:] += g[co1][cell] * x-window at the cell's arg-max pixel
+#if defined(CNN_ABL) && CNN_ABL == 1
+        for (int c = grp; c < 0; c += CNN_NT / 8) {
+#else
         for (int c = grp; c < PC; c += CNN_NT / 8) {
+#endif
             const float gv = gbuf[co1 * PC + c];
             if (gv != 0.0f) {
                 const int am = ambuf[co1 * PC + c];
@@ -350,14 +424,21 @@ __global__ void __launch_bounds__(CNN_NT, 2) rs_cnn_bwd_kernel(CnnIn in, const f
     }
 }
 
-inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE + (cin * 9 + 1) * C1 + (C1 * 9 + 1) * C2); }
+inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE); }
 inline size_t bwd_lds(int cin) {
-    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC + C2 * 9 * C1) * 4 + C1 * PC;
+    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC;
     size_t red = (size_t)(3 * C1 * (cin * 9 + 1) + 3 * 16 * 80) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
-inline int cnn_grid(long long S, int per_cu) {      // persistent: as many workgroups as fit per CU, each strides over the batch
-    const long long cap = 256 * per_cu;
+// persistent grid: exactly as many workgroups as are resident at once (occupancy query x CU count), so no second,
+// half-empty round of workgroups trails the first; each workgroup strides over the batch
+template <typename K>
+inline int cnn_grid(K kernel, size_t lds, long long S) {
+    int per_cu = 0, dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CNN_NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const long long cap = (long long)cus * per_cu;
     return (int)(S < cap ? S : cap);
 }
 
@@ -366,32 +447,42 @@ inline int cnn_grid(long long S, int per_cu) {      // persistent: as many workg
 extern "C" {
 
 int32_t rs_cnn_trunk_slab_row(int32_t in_channels) { return C1 * in_channels * 9 + C1 + C2 * 72 + C2; }
-int32_t rs_cnn_trunk_slab_rows(int64_t num_samples) { return cnn_grid(num_samples, 3); }
+int32_t rs_cnn_trunk_slab_rows(int64_t num_samples, int32_t in_channels) {
+    return in_channels == 6 ? cnn_grid(rs_cnn_bwd_kernel<6>, bwd_lds(6), num_samples) : cnn_grid(rs_cnn_bwd_kernel<4>, bwd_lds(4), num_samples);
+}
+int32_t rs_cnn_trunk_scratch_floats(int32_t in_channels) { return WT_TOTAL(in_channels); }
 
 int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                          int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
-                         float* p1, uint8_t* amax, rs_stream_t stream) {
-    if (!maps || !w1 || !b1 || !w2 || !b2 || !a2 || num_samples < 0 || ((p1 == nullptr) != (amax == nullptr))) return RS_ERR_INVALID_ARG;
+                         float* p1, uint8_t* amax, float* wscratch, rs_stream_t stream) {
+    if (!maps || !w1 || !b1 || !w2 || !b2 || !a2 || !wscratch || num_samples < 0 || ((p1 == nullptr) != (amax == nullptr))) return RS_ERR_INVALID_ARG;
     if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
     if (num_samples == 0) return RS_OK;
     CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
     hipStream_t s = (hipStream_t)stream;
-    const int grid = cnn_grid(num_samples, 4);
-    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(grid), dim3(CNN_NT), fwd_lds(6), s, in, w1, b1, w2, b2, a2, p1, amax);
-    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(grid), dim3(CNN_NT), fwd_lds(4), s, in, w1, b1, w2, b2, a2, p1, amax);
+    const int cin = agent >= 0 ? 6 : 4;
+    hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, w1, b1, w2, b2, wscratch);
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, fwd_lds(6), num_samples)), dim3(CNN_NT),
+                                       fwd_lds(6), s, in, wscratch, a2, p1, amax);
+    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, fwd_lds(4), num_samples)), dim3(CNN_NT),
+                            fwd_lds(4), s, in, wscratch, a2, p1, amax);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
 int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                           int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
-                          const uint8_t* amax, float* slab, rs_stream_t stream) {
-    if (!maps || !w2 || !da2 || !a2 || !p1 || !amax || !slab || num_samples <= 0) return RS_ERR_INVALID_ARG;
+                          const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream) {
+    if (!maps || !w2 || !da2 || !a2 || !p1 || !amax || !slab || !wscratch || num_samples <= 0) return RS_ERR_INVALID_ARG;
     if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
     CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
     hipStream_t s = (hipStream_t)stream;
-    const int grid = cnn_grid(num_samples, 3);
-    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(grid), dim3(CNN_NT), bwd_lds(6), s, in, w2, da2, a2, p1, amax, slab);
-    else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(grid), dim3(CNN_NT), bwd_lds(4), s, in, w2, da2, a2, p1, amax, slab);
+    const int cin = agent >= 0 ? 6 : 4;
+    hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, (const float*)nullptr, (const float*)nullptr, w2,
+                       (const float*)nullptr, wscratch);
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(cnn_grid(rs_cnn_bwd_kernel<6>, bwd_lds(6), num_samples)), dim3(CNN_NT),
+                                       bwd_lds(6), s, in, wscratch, da2, a2, p1, amax, slab);
+    else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(cnn_grid(rs_cnn_bwd_kernel<4>, bwd_lds(4), num_samples)), dim3(CNN_NT),
+                            bwd_lds(4), s, in, wscratch, da2, a2, p1, amax, slab);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

@@ -124,10 +124,11 @@ class ConvTrunk(torch.autograd.Function):
         p1 = torch.empty(S, 8, 169, dtype=torch.float32, device=maps.device) if train else None
         amax = torch.empty(S, 8, 169, dtype=torch.uint8, device=maps.device) if train else None
         stream = torch.cuda.current_stream(maps.device).cuda_stream
+        wt = torch.empty(lib.rs_cnn_trunk_scratch_floats(6 if agent >= 0 else 4), dtype=torch.float32, device=maps.device)
         _lib.check(lib.rs_cnn_trunk_forward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
                                             pcells.data_ptr() if agent >= 0 else None, A, agent, S, w1c.data_ptr(), b1c.data_ptr(),
                                             w2c.data_ptr(), b2c.data_ptr(), a2.data_ptr(), p1.data_ptr() if train else None,
-                                            amax.data_ptr() if train else None, stream), "rs_cnn_trunk_forward")
+                                            amax.data_ptr() if train else None, wt.data_ptr(), stream), "rs_cnn_trunk_forward")
         if train:
             ctx.save_for_backward(maps, cells if agent >= 0 else maps, pcells if agent >= 0 else maps, w2c, a2, p1, amax)
             ctx.agent, ctx.A, ctx.cin = agent, A, (6 if agent >= 0 else 4)
@@ -139,12 +140,14 @@ class ConvTrunk(torch.autograd.Function):
         maps, cells, pcells, w2c, a2, p1, amax = ctx.saved_tensors
         S, cin, agent = maps.shape[0], ctx.cin, ctx.agent
         da2 = da2.contiguous()
-        rows, row = lib.rs_cnn_trunk_slab_rows(S), lib.rs_cnn_trunk_slab_row(cin)
+        rows, row = lib.rs_cnn_trunk_slab_rows(S, cin), lib.rs_cnn_trunk_slab_row(cin)
         slab = torch.empty(rows, row, dtype=torch.float32, device=maps.device)
         stream = torch.cuda.current_stream(maps.device).cuda_stream
         _lib.check(lib.rs_cnn_trunk_backward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
                                              pcells.data_ptr() if agent >= 0 else None, ctx.A, agent, S, w2c.data_ptr(),
-                                             da2.data_ptr(), a2.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(), stream),
+                                             da2.data_ptr(), a2.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(),
+                                             torch.empty(lib.rs_cnn_trunk_scratch_floats(cin), dtype=torch.float32,
+                                                         device=maps.device).data_ptr(), stream),
                    "rs_cnn_trunk_backward")
         g = slab.sum(dim=0)
         n1 = 8 * cin * 9

@@ -7,7 +7,7 @@ from radiation_ppo_amd.maps import CNNCritic
 N, T, L, A = 256, 240, 120, 4
 env = RadSearchVec(N, number_agents=A, obstruction_count=-1, enforce_grid_boundaries=True, seed=289714752)
 gc = CNNCritic().cuda(); gco = torch.optim.Adam(gc.parameters(), lr=1e-3)
-ag = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=3, train_v_iters=3) for i in range(A)}
+ag = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=6, train_v_iters=6) for i in range(A)}
 col = CNNCollector(env, ag, T, L, True)
 for it in range(2):
     t0 = time.perf_counter(); col.collect(); torch.cuda.synchronize(); t1 = time.perf_counter()
