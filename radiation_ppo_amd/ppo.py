@@ -92,7 +92,9 @@ class FusedPPOGrad:
         self.lib = _lib.load()
         self.ac = ac
         dev = next(ac.parameters()).device
-        self.grads = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)
+        # one flat bucket for the data-parallel exchange: [gradients | the 5 loss statistics as float32]
+        self.bucket = torch.zeros(N_PARAMS + 8, dtype=torch.float32, device=dev)
+        self.grads = self.bucket[:N_PARAMS]
         self.stats = torch.zeros(5, dtype=torch.float64, device=dev)
         self.ws = torch.empty(self.lib.rs_ppo_grad_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
         self._ws_ptr = self.ws.data_ptr() + (-self.ws.data_ptr()) % 256
@@ -139,6 +141,14 @@ class FusedPPOGrad:
                                         self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
                                         torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
         return self.stats, self.grads
+
+    def allreduce(self) -> None:
+        """mpi_avg_grads (ppo.py:1256) + mpi_avg(kl) (:1250) as ONE RCCL all-reduce per Adam step: the statistics ride
+        in the tail of the gradient bucket (xGMI all-reduces of this size are latency bound, so the count matters,
+        not the bytes).  The loss weights already carry 1/(global env count): SUM over ranks = the reference's average."""
+        self.bucket[N_PARAMS:N_PARAMS + 5] = self.stats
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        self.stats.copy_(self.bucket[N_PARAMS:N_PARAMS + 5])
 
     def assign_grads(self) -> None:
         for p, g in self.views:
@@ -332,8 +342,7 @@ class VecAgentPPO:
         for _ in range(self.train_pi_iters):
             stats, grads = f(X, act, adv, ret, logp_old, w, self.clip_ratio, self.alpha, use_stop_flag=True)
             if _world() > 1:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM)           # mpi_avg(kl) (ppo.py:1250)
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM)           # mpi_avg_grads (ppo.py:1256): one flat bucket
+                f.allreduce()
             f.adam_step(lr, thr)
         kk, stopped, _, last = f.read_state()
         self.epochs_done += 1

@@ -1,0 +1,32 @@
+"""Worker for tests/test_bench_dist_gpu.py::test_data_parallel_equals_single_process: one PPO iteration (fused rollout +
+GAE + device-side update) on this rank's shard of the envs; rank 0 writes the resulting parameters."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out, total_envs = sys.argv[1], int(sys.argv[2])
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+torch.cuda.set_device(0)
+if world > 1:
+    dist.init_process_group(backend="gloo")
+from radiation_ppo_amd.envs import RadSearchVec                      # noqa: E402
+from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO        # noqa: E402
+
+N, T, L = total_envs // world, 48, 12
+torch.manual_seed(1234)                                              # same initial policy on every rank / world size
+env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)
+agents = {0: VecAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, train_pi_iters=6, actor_learning_rate=3e-3)}
+agents[0].sync_params()
+col = FusedCollector(env, agents, T, L)
+col.collect()
+res = col.update()[0]
+if rank == 0:
+    flat = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()]).cpu()
+    torch.save({"params": flat, "kl": res.kl_divergence, "loss": res.loss_policy, "stop": res.stop_iteration,
+                "entropy": res.Entropy}, out)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()

@@ -24,3 +24,24 @@ def test_bench_two_ranks_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 480 * 512 * 2) < 1.0     # both shards counted
+
+
+def test_data_parallel_equals_single_process(tmp_path):
+    """Sharding is transparent: 2 ranks x 64 envs (env_id_base = rank * 64, one bucketed all-reduce of gradients + loss
+    statistics per Adam step, global advantage statistics) end one PPO iteration with the same parameters, KL and
+    loss as 1 process x 128 envs -- Philox streams are keyed by the global env id, the loss weights by the global
+    env count.  Tolerance: fp32 with a different summation order (per-rank partial sums)."""
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "_dp_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r1 = subprocess.run([sys.executable, worker, one, "128"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29741", worker, two, "128"], cwd=ROOT, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = torch.load(one), torch.load(two)
+    assert a["stop"] == b["stop"]
+    assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["entropy"] - b["entropy"]) < 1e-5
+    assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=2e-5), float((a["params"] - b["params"]).abs().max())
