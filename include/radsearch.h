@@ -262,8 +262,9 @@ int rs_maps_field(rs_maps* m, const char* name, void** dev_ptr, int32_t* elem_by
  *               -1, one-hot(cells[s][agent]), combined - location, readings, visits, obstacles}; cells/pcells [S][A] int64
  *   agent  < 0: critic input (4 channels) = maps as they are; cells/pcells ignored
  *   w1 [8][Cin][3][3], b1 [8], w2 [16][8][3][3], b2 [16]: torch Conv2d layouts
- *   a2 [S][2704] (= Flatten of the ReLU'd conv2 output); p1 [S][8][169] and amax [S][8][169] (pooled activations and
- *   the winning pixel of each 2x2 window) are written when non-NULL (both or neither) and are what backward consumes.
+ *   a2 [S][2704] (= Flatten of the ReLU'd conv2 output).  For training (all three non-NULL, or all NULL) the forward
+ *   also writes what backward consumes: p1 [S][169][8] float32 pooled activations, amax [S][169][8] uint8 the winning
+ *   pixel (0..3, row-major, first maximum) of each 2x2 pool window, relu_mask [S][169] uint16 bit c = (a2 channel c > 0).
  * Backward: da2 [S][2704] = dL/d(a2); slab [rs_cnn_trunk_slab_rows(S, Cin)][rs_cnn_trunk_slab_row(Cin)] receives
  * per-workgroup partial sums laid out {dW1 8*Cin*9 | db1 8 | dW2 1152 | db2 16}; the caller sums the rows.
  * wscratch: device scratch of rs_cnn_trunk_scratch_floats(Cin) floats (the weights re-laid-out for scalar loads). */
@@ -272,9 +273,9 @@ int32_t rs_cnn_trunk_slab_rows(int64_t num_samples, int32_t in_channels);
 int32_t rs_cnn_trunk_scratch_floats(int32_t in_channels);
 int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                          int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
-                         float* p1, uint8_t* amax, float* wscratch, rs_stream_t stream);
+                         float* p1, uint8_t* amax, uint16_t* relu_mask, float* wscratch, rs_stream_t stream);
 int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
-                          int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
+                          int64_t num_samples, const float* w2, const float* da2, const uint16_t* relu_mask, const float* p1,
                           const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream);
 
 #ifdef __cplusplus

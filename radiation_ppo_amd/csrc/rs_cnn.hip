@@ -27,7 +27,7 @@
 namespace {
 
 #ifndef CNN_BWD_WAVES
-#define CNN_BWD_WAVES 2
+#define CNN_BWD_WAVES 3
 #endif
 #ifndef CNN_BWD_PREFETCH
 #define CNN_BWD_PREFETCH 1
@@ -35,7 +35,7 @@ namespace {
 constexpr int CNN_NT = 192;                 // threads per workgroup (3 waves); 169 of them own a pooled cell / pixel
 constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
 constexpr int PW = 13, PC = 169;            // pooled side and cells
-constexpr int XP_RS = 28, XP_PLANE = 28 * 28;   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
+constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 4;   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
                                                 // border only feeds conv1 row/column 26, which the pool drops; even stride (b64 reads)
 constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
@@ -149,7 +149,8 @@ __device__ __forceinline__ void cnn_clear_onehots(float* xp, int loc, int pc) {
 // row-major order; first maximum wins like torch's CPU max_pool2d).
 template <int CIN>
 __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
-                                                            float* __restrict__ p1g, uint8_t* __restrict__ amax) {
+                                                            float* __restrict__ p1g, uint8_t* __restrict__ amax,
+                                                            uint16_t* __restrict__ relu_mask) {
     extern __shared__ __align__(16) float smem[];
     float* xp = smem;                               // [CIN][28][28]
     float* pp = xp + CIN * XP_PLANE;                // [8][15][15]
@@ -208,6 +209,8 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
                             }
                     }
             }
+            float pbest[C1];
+            uint32_t pidx[2] = {0u, 0u};
 #pragma unroll
             for (int co = 0; co < C1; ++co) {
                 const float bb = b1c[co];
@@ -219,10 +222,14 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
                     if (v > best) { best = v; idx = p; }
                 }
                 pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = best;
-                if (p1g) {
-                    p1g[((size_t)s * C1 + co) * PC + tid] = best;
-                    amax[((size_t)s * C1 + co) * PC + tid] = (uint8_t)idx;
-                }
+                pbest[co] = best;
+                pidx[co >> 2] |= (uint32_t)idx << (8 * (co & 3));
+            }
+            if (p1g) {                  // cell-major rows: 32 B of p1 and 8 B of amax per thread, contiguous across the wave
+                v4f* dst = reinterpret_cast<v4f*>(p1g + ((size_t)s * PC + tid) * C1);
+                dst[0] = (v4f){pbest[0], pbest[1], pbest[2], pbest[3]};
+                dst[1] = (v4f){pbest[4], pbest[5], pbest[6], pbest[7]};
+                *reinterpret_cast<uint2*>(amax + ((size_t)s * PC + tid) * C1) = make_uint2(pidx[0], pidx[1]);
             }
         }
         __syncthreads();
@@ -241,9 +248,14 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
 #pragma unroll
                         for (int q = 0; q < C2; ++q) acc2[q] = __builtin_fmaf(w2c[((ci * 3 + ky) * 3 + kx) * C2 + q], v, acc2[q]);
                     }
+            uint32_t live = 0u;
 #pragma unroll
-            for (int co = 0; co < C2; ++co)
-                a2[(size_t)s * FLAT + co * PC + tid] = fmaxf(acc2[co] + b2c[co], 0.0f);
+            for (int co = 0; co < C2; ++co) {
+                const float o = fmaxf(acc2[co] + b2c[co], 0.0f);
+                a2[(size_t)s * FLAT + co * PC + tid] = o;
+                live |= (o > 0.0f ? 1u : 0u) << co;
+            }
+            if (relu_mask) relu_mask[(size_t)s * PC + tid] = (uint16_t)live;       // what backward needs of a2: its sign
         }
         cnn_clear_onehots<CIN>(xp, loc, pc);
         __syncthreads();
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
 // [dW1 8*CIN*9 | db1 8 | dW2 16*72 | db2 16], torch weight order).
 template <int CIN>
 __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ wt, const float* __restrict__ da2,
-                                                            const float* __restrict__ a2, const float* __restrict__ p1g,
+                                                            const uint16_t* __restrict__ relu_mask, const float* __restrict__ p1g,
                                                             const uint8_t* __restrict__ amax, float* __restrict__ slab) {
     extern __shared__ __align__(16) float smem[];
     constexpr int K1 = CIN * 9;
@@ -263,7 +275,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     float* pp = xp + CIN * XP_PLANE;                // [8][15][15]   padded P1
     float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
     float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
-    uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [8][169]
+    uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [169][8]
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;
@@ -274,11 +286,13 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     v4f accw[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) accw[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-    // dW1 row of channel co1 (+ db1 in slot K1): this thread's share of the cells
-    float aw1[K1 + 1];
+    // dW1: thread = (output channel co1, input channel c0) x cell group; 9 taps (+ db1 on the c0 == 0 threads)
+    constexpr int NCOMBO = C1 * CIN, NGRP = CNN_NT / NCOMBO;     // 48 x 4 (actor), 32 x 6 (critic)
+    float aw1[10];
 #pragma unroll
-    for (int k = 0; k <= K1; ++k) aw1[k] = 0.0f;
-    const int co1 = tid & 7, grp = tid >> 3;        // 24 groups of 8 channels
+    for (int k = 0; k < 10; ++k) aw1[k] = 0.0f;
+    const int combo = tid % NCOMBO, grp = tid / NCOMBO;
+    const int co1 = combo & 7, c0 = combo >> 3;
     // MFMA operand coordinates of this lane
     const int mrow = lane & 15, mk = lane >> 4;
     int bci[5], bky[5], bkx[5], bmode[5];           // B column n = 16*tile + mrow -> (ci,ky,kx) / ones / zero
@@ -290,21 +304,18 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
         bci[t] = nn / 9; bky[t] = (nn % 9) / 3; bkx[t] = nn % 3;
     }
     CnnFetch f;
-    float fp1[C1], fa2[C2], fda2[C2];
-    uint8_t fam[C1];
+    v4f fp1a = (v4f){0.f, 0.f, 0.f, 0.f}, fp1b = fp1a;
+    float fda2[C2];
+    uint2 fam = make_uint2(0u, 0u);
+    uint32_t fmask = 0u;
     auto fetch_acts = [&](long long s) {
         if (own) {
+            const v4f* src = reinterpret_cast<const v4f*>(p1g + ((size_t)s * PC + tid) * C1);
+            fp1a = src[0]; fp1b = src[1];
+            fam = *reinterpret_cast<const uint2*>(amax + ((size_t)s * PC + tid) * C1);
+            fmask = relu_mask[(size_t)s * PC + tid];
 #pragma unroll
-            for (int co = 0; co < C1; ++co) {
-                fp1[co] = p1g[((size_t)s * C1 + co) * PC + tid];
-                fam[co] = amax[((size_t)s * C1 + co) * PC + tid];
-            }
-#pragma unroll
-            for (int co = 0; co < C2; ++co) {
-                const size_t o = (size_t)s * FLAT + co * PC + tid;
-                fa2[co] = a2[o];
-                fda2[co] = da2[o];
-            }
+            for (int co = 0; co < C2; ++co) fda2[co] = da2[(size_t)s * FLAT + co * PC + tid];
         }
     };
     if ((long long)blockIdx.x < in.S) { cnn_fetch<CIN>(in, blockIdx.x, f); if (CNN_BWD_PREFETCH) fetch_acts(blockIdx.x); }
@@ -314,13 +325,14 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
         cnn_stage<CIN>(f, xp);
         if (own) {
 #pragma unroll
-            for (int co = 0; co < C1; ++co) {
-                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1[co];
-                ambuf[co * PC + tid] = fam[co];
+            for (int co = 0; co < 4; ++co) {
+                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1a[co];
+                pp[(4 + co) * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1b[co];
             }
+            *reinterpret_cast<uint2*>(ambuf + tid * C1) = fam;
 #pragma unroll
             for (int co = 0; co < C2; ++co)
-                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = (fa2[co] > 0.0f) ? fda2[co] : 0.0f;     // ReLU gate
+                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
         }
         __syncthreads();
         cnn_set_onehots<CIN>(xp, loc, pc);
@@ -367,44 +379,42 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
                 gbuf[ci * PC + tid] = (pp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1] > 0.0f) ? g[ci] : 0.0f;
         }
         __syncthreads();
-        // ---- dW1[co1][:] += g[co1][cell] * x-window at the cell's arg-max pixel
-#if defined(CNN_ABL) && CNN_ABL == 1
-        for (int c = grp; c < 0; c += CNN_NT / 8) {
-#else
-        for (int c = grp; c < PC; c += CNN_NT / 8) {
-#endif
-            const float gv = gbuf[co1 * PC + c];
-            if (gv != 0.0f) {
-                const int am = ambuf[co1 * PC + c];
-                const int cy = c / PW, cx = c - cy * PW;
-                const float* base = xp + (2 * cy + (am >> 1)) * XP_RS + 2 * cx + (am & 1);
+        // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel.  Four cells in flight per
+        // trip and no branch on g == 0 (a dead cell just adds zeros) so the g -> argmax -> window -> FMA chains overlap.
+#if !(defined(CNN_ABL) && CNN_ABL == 1)
+        for (int c = grp; c < PC; c += 4 * NGRP) {
+            float gv[4];
+            const float* base[4];
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci)
+            for (int u = 0; u < 4; ++u) {
+                const int cu = c + u * NGRP;
+                const bool ok = cu < PC;
+                const int cq = ok ? cu : grp;
+                gv[u] = ok ? gbuf[co1 * PC + cq] : 0.0f;
+                const int am = ambuf[cq * C1 + co1];
+                const int cy = cq / PW, cx = cq - cy * PW;
+                base[u] = xp + c0 * XP_PLANE + (2 * cy + (am >> 1)) * XP_RS + 2 * cx + (am & 1);
+            }
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-                            aw1[(ci * 3 + ky) * 3 + kx] = __builtin_fmaf(gv, base[ci * XP_PLANE + ky * XP_RS + kx], aw1[(ci * 3 + ky) * 3 + kx]);
-                aw1[K1] += gv;
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) aw1[ky * 3 + kx] = __builtin_fmaf(gv[u], base[u][ky * XP_RS + kx], aw1[ky * 3 + kx]);
+                aw1[9] += gv[u];
             }
         }
+#endif
         __syncthreads();
         cnn_clear_onehots<CIN>(xp, loc, pc);
         __syncthreads();
     }
     // ---- workgroup reduction (fixed order) -> slab row
-    // (the 8 lanes of a wave that share co1 are first summed with a fixed xor tree)
     __syncthreads();
-    float* red = smem;                               // aliases the image buffers: [3 waves][8][K1+1] then [3][16][80]
-    float* red2 = red + 3 * C1 * (K1 + 1);
+    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][10] then [3][16][80]
+    float* red2 = red + CNN_NT * 10;
 #pragma unroll
-    for (int k = 0; k <= K1; ++k) {
-        float v = aw1[k];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < C1) red[(wave * C1 + lane) * (K1 + 1) + k] = v;
-    }
+    for (int k = 0; k < 10; ++k) red[tid * 10 + k] = aw1[k];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
@@ -412,10 +422,14 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     __syncthreads();
     constexpr int ROW = C1 * K1 + C1 + C2 * 72 + C2;
     float* out = slab + (size_t)blockIdx.x * ROW;
-    for (int e = tid; e < C1 * (K1 + 1); e += CNN_NT) {
-        const int c = e / (K1 + 1), k = e - c * (K1 + 1);
-        const float sum = red[(0 * C1 + c) * (K1 + 1) + k] + red[(1 * C1 + c) * (K1 + 1) + k] + red[(2 * C1 + c) * (K1 + 1) + k];
-        if (k < K1) out[c * K1 + k] = sum; else out[C1 * K1 + c] = sum;
+    for (int e = tid; e < NCOMBO * 10; e += CNN_NT) {
+        const int cb = e / 10, k = e - cb * 10;
+        float sum = 0.0f;
+#pragma unroll
+        for (int gi = 0; gi < NGRP; ++gi) sum += red[(gi * NCOMBO + cb) * 10 + k];
+        const int o1 = cb & 7, i0 = cb >> 3;
+        if (k < 9) out[o1 * K1 + i0 * 9 + k] = sum;
+        else if (i0 == 0) out[C1 * K1 + o1] = sum;
     }
     for (int e = tid; e < C2 * 73; e += CNN_NT) {
         const int co = e / 73, n = e - co * 73;
@@ -427,7 +441,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
 inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE); }
 inline size_t bwd_lds(int cin) {
     size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC;
-    size_t red = (size_t)(3 * C1 * (cin * 9 + 1) + 3 * 16 * 80) * 4;
+    size_t red = (size_t)(CNN_NT * 10 + 3 * 16 * 80) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
 // persistent grid: exactly as many workgroups as are resident at once (occupancy query x CU count), so no second,
@@ -454,8 +468,9 @@ int32_t rs_cnn_trunk_scratch_floats(int32_t in_channels) { return WT_TOTAL(in_ch
 
 int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                          int64_t num_samples, const float* w1, const float* b1, const float* w2, const float* b2, float* a2,
-                         float* p1, uint8_t* amax, float* wscratch, rs_stream_t stream) {
-    if (!maps || !w1 || !b1 || !w2 || !b2 || !a2 || !wscratch || num_samples < 0 || ((p1 == nullptr) != (amax == nullptr))) return RS_ERR_INVALID_ARG;
+                         float* p1, uint8_t* amax, uint16_t* relu_mask, float* wscratch, rs_stream_t stream) {
+    if (!maps || !w1 || !b1 || !w2 || !b2 || !a2 || !wscratch || num_samples < 0) return RS_ERR_INVALID_ARG;
+    if ((p1 == nullptr) != (amax == nullptr) || (p1 == nullptr) != (relu_mask == nullptr)) return RS_ERR_INVALID_ARG;
     if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
     if (num_samples == 0) return RS_OK;
     CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
@@ -463,16 +478,16 @@ int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t*
     const int cin = agent >= 0 ? 6 : 4;
     hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, w1, b1, w2, b2, wscratch);
     if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, fwd_lds(6), num_samples)), dim3(CNN_NT),
-                                       fwd_lds(6), s, in, wscratch, a2, p1, amax);
+                                       fwd_lds(6), s, in, wscratch, a2, p1, amax, relu_mask);
     else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, fwd_lds(4), num_samples)), dim3(CNN_NT),
-                            fwd_lds(4), s, in, wscratch, a2, p1, amax);
+                            fwd_lds(4), s, in, wscratch, a2, p1, amax, relu_mask);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
 int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
-                          int64_t num_samples, const float* w2, const float* da2, const float* a2, const float* p1,
+                          int64_t num_samples, const float* w2, const float* da2, const uint16_t* relu_mask, const float* p1,
                           const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream) {
-    if (!maps || !w2 || !da2 || !a2 || !p1 || !amax || !slab || !wscratch || num_samples <= 0) return RS_ERR_INVALID_ARG;
+    if (!maps || !w2 || !da2 || !relu_mask || !p1 || !amax || !slab || !wscratch || num_samples <= 0) return RS_ERR_INVALID_ARG;
     if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
     CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
     hipStream_t s = (hipStream_t)stream;
@@ -480,9 +495,9 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
     hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, (const float*)nullptr, (const float*)nullptr, w2,
                        (const float*)nullptr, wscratch);
     if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(cnn_grid(rs_cnn_bwd_kernel<6>, bwd_lds(6), num_samples)), dim3(CNN_NT),
-                                       bwd_lds(6), s, in, wscratch, da2, a2, p1, amax, slab);
+                                       bwd_lds(6), s, in, wscratch, da2, relu_mask, p1, amax, slab);
     else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(cnn_grid(rs_cnn_bwd_kernel<4>, bwd_lds(4), num_samples)), dim3(CNN_NT),
-                            bwd_lds(4), s, in, wscratch, da2, a2, p1, amax, slab);
+                            bwd_lds(4), s, in, wscratch, da2, relu_mask, p1, amax, slab);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

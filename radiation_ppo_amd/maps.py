@@ -121,23 +121,25 @@ class ConvTrunk(torch.autograd.Function):
         assert w1c.shape == (8, 6 if agent >= 0 else 4, 3, 3) and w2c.shape == (16, 8, 3, 3)
         train = any(ctx.needs_input_grad[4:8])
         a2 = torch.empty(S, 2704, dtype=torch.float32, device=maps.device)
-        p1 = torch.empty(S, 8, 169, dtype=torch.float32, device=maps.device) if train else None
-        amax = torch.empty(S, 8, 169, dtype=torch.uint8, device=maps.device) if train else None
+        p1 = torch.empty(S, 169, 8, dtype=torch.float32, device=maps.device) if train else None
+        amax = torch.empty(S, 169, 8, dtype=torch.uint8, device=maps.device) if train else None
+        mask = torch.empty(S, 169, dtype=torch.int16, device=maps.device) if train else None
         stream = torch.cuda.current_stream(maps.device).cuda_stream
         wt = torch.empty(lib.rs_cnn_trunk_scratch_floats(6 if agent >= 0 else 4), dtype=torch.float32, device=maps.device)
         _lib.check(lib.rs_cnn_trunk_forward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
                                             pcells.data_ptr() if agent >= 0 else None, A, agent, S, w1c.data_ptr(), b1c.data_ptr(),
                                             w2c.data_ptr(), b2c.data_ptr(), a2.data_ptr(), p1.data_ptr() if train else None,
-                                            amax.data_ptr() if train else None, wt.data_ptr(), stream), "rs_cnn_trunk_forward")
+                                            amax.data_ptr() if train else None, mask.data_ptr() if train else None, wt.data_ptr(),
+                                            stream), "rs_cnn_trunk_forward")
         if train:
-            ctx.save_for_backward(maps, cells if agent >= 0 else maps, pcells if agent >= 0 else maps, w2c, a2, p1, amax)
+            ctx.save_for_backward(maps, cells if agent >= 0 else maps, pcells if agent >= 0 else maps, w2c, mask, p1, amax)
             ctx.agent, ctx.A, ctx.cin = agent, A, (6 if agent >= 0 else 4)
         return a2
 
     @staticmethod
     def backward(ctx, da2):
         lib = _lib.load()
-        maps, cells, pcells, w2c, a2, p1, amax = ctx.saved_tensors
+        maps, cells, pcells, w2c, mask, p1, amax = ctx.saved_tensors
         S, cin, agent = maps.shape[0], ctx.cin, ctx.agent
         da2 = da2.contiguous()
         rows, row = lib.rs_cnn_trunk_slab_rows(S, cin), lib.rs_cnn_trunk_slab_row(cin)
@@ -145,7 +147,7 @@ class ConvTrunk(torch.autograd.Function):
         stream = torch.cuda.current_stream(maps.device).cuda_stream
         _lib.check(lib.rs_cnn_trunk_backward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
                                              pcells.data_ptr() if agent >= 0 else None, ctx.A, agent, S, w2c.data_ptr(),
-                                             da2.data_ptr(), a2.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(),
+                                             da2.data_ptr(), mask.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(),
                                              torch.empty(lib.rs_cnn_trunk_scratch_floats(cin), dtype=torch.float32,
                                                          device=maps.device).data_ptr(), stream),
                    "rs_cnn_trunk_backward")

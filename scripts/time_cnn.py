@@ -12,7 +12,7 @@ st = torch.cuda.current_stream().cuda_stream
 for cin, agent in ((6, 0), (4, -1)):
     w1 = torch.randn(8, cin, 3, 3, device="cuda") * 0.2; b1 = torch.rand(8, device="cuda") * 0.1
     w2 = torch.randn(16, 8, 3, 3, device="cuda") * 0.1; b2 = torch.rand(16, device="cuda") * 0.1
-    a2 = torch.empty(S, 2704, device="cuda"); p1 = torch.empty(S, 8, 169, device="cuda"); am = torch.empty(S, 8, 169, dtype=torch.uint8, device="cuda")
+    a2 = torch.empty(S, 2704, device="cuda"); p1 = torch.empty(S, 169, 8, device="cuda"); am = torch.empty(S, 169, 8, dtype=torch.uint8, device="cuda"); mk = torch.empty(S, 169, dtype=torch.int16, device="cuda")
     da2 = torch.randn(S, 2704, device="cuda")
     rows, row = lib.rs_cnn_trunk_slab_rows(S, cin), lib.rs_cnn_trunk_slab_row(cin)
     slab = torch.empty(rows, row, device="cuda")
@@ -20,9 +20,9 @@ for cin, agent in ((6, 0), (4, -1)):
     wt = torch.empty(lib.rs_cnn_trunk_scratch_floats(cin), device="cuda")
     def fwd(train):
         lib.rs_cnn_trunk_forward(maps.data_ptr(), cp[0], cp[1], A, agent, S, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                 a2.data_ptr(), p1.data_ptr() if train else None, am.data_ptr() if train else None, wt.data_ptr(), st)
+                                 a2.data_ptr(), p1.data_ptr() if train else None, am.data_ptr() if train else None, mk.data_ptr() if train else None, wt.data_ptr(), st)
     def bwd():
-        lib.rs_cnn_trunk_backward(maps.data_ptr(), cp[0], cp[1], A, agent, S, w2.data_ptr(), da2.data_ptr(), a2.data_ptr(), p1.data_ptr(),
+        lib.rs_cnn_trunk_backward(maps.data_ptr(), cp[0], cp[1], A, agent, S, w2.data_ptr(), da2.data_ptr(), mk.data_ptr(), p1.data_ptr(),
                                   am.data_ptr(), slab.data_ptr(), wt.data_ptr(), st)
     for name, fn in (("fwd_infer", lambda: fwd(False)), ("fwd_train", lambda: fwd(True)), ("bwd", bwd)):
         fn(); torch.cuda.synchronize()
