@@ -88,6 +88,12 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         for (int k = 0; k < RS_IN; ++k) x[k] = B.x[(size_t)mm * RS_IN + k];
         x[11] = 1.0f;                     // constant input: column 11 of w1b carries b1, and column 11 of dW1 is db1
         const float wi = valid ? B.w[mm] : 0.0f;
+        // x^T goes to its LDS tile right away (R6 reads it at the end of the group), so the 12 input registers die
+        // after layer 1 instead of living through the whole backward pass (they were what spilled)
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < RS_IN_PAD; ++k) St[k * RS_T2 + c] = x[k];
+        }
 
         // ---------------- forward ----------------
         f32x16 H1[2], H2[2];
@@ -209,12 +215,12 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         rs_stage32(Qt + 32 * RS_T2, H2[1], c, h);
         if (h == 0) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) St[o * RS_T2 + c] = dz[o];
+            for (int o = 0; o < NOUT; ++o) Pt[o * RS_T2 + c] = dz[o];      // dz^T borrows Pt (free until R3)
         }
         rs_wave_sync();
         // R2: dW3[o][unit] += sum_n dz[o][n] h2[unit][n]  (16x16x4, 8 k-steps)  ||  dh2 -> dpre2 (in place of H2)
         {
-            float a_c = (l15 < NOUT) ? St[l15 * RS_T2 + l4] : 0.0f;
+            float a_c = (l15 < NOUT) ? Pt[l15 * RS_T2 + l4] : 0.0f;
             float b_c[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) b_c[u] = Qt[(16 * u + l15) * RS_T2 + l4];
@@ -222,7 +228,7 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
             for (int s = 0; s < 8; ++s) {
                 float a_n = 0.f, b_n[4] = {0.f, 0.f, 0.f, 0.f};
                 if (s + 1 < 8) {
-                    a_n = (l15 < NOUT) ? St[l15 * RS_T2 + 4 * (s + 1) + l4] : 0.0f;
+                    a_n = (l15 < NOUT) ? Pt[l15 * RS_T2 + 4 * (s + 1) + l4] : 0.0f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) b_n[u] = Qt[(16 * u + l15) * RS_T2 + 4 * (s + 1) + l4];
                 }
@@ -282,11 +288,6 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         rs_stage32(Qt, H1[0], c, h);
         rs_stage32(Qt + 32 * RS_T2, H1[1], c, h);
         rs_stage32(Pt, H2[0], c, h);
-        if (h == 0) {
-#pragma unroll
-            for (int k = 0; k < RS_IN; ++k) St[k * RS_T2 + c] = x[k];
-            St[11 * RS_T2 + c] = 1.0f;                       // x[11] := 1 -> column 11 of dW1 is db1
-        }
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll

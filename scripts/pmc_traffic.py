@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace, csv output) of
+`python3 scripts/prof_update.py N` into profiles/<name>.json: HBM bytes per launch per kernel.
+Correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte fabric reads as 64 B on gfx950 -> x2;
+WRITE_SIZE as is; unit KB."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def load(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            if "rs_" not in name:
+                continue
+            short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            if "rs_step_kernel" in short:
+                short += "@grid%s" % r["Grid_Size"]
+            acc[short].append(float(r["Counter_Value"]))
+    return acc
+
+
+fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+kern = {}
+for k in sorted(set(fe) | set(wr)):
+    # steady state: drop the first launch of each kernel (cold caches), average the rest
+    f = fe.get(k, [0.0]); w = wr.get(k, [0.0])
+    f = f[1:] if len(f) > 1 else f
+    w = w[1:] if len(w) > 1 else w
+    fk, wk = sum(f) / len(f), sum(w) / len(w)
+    kern[k] = {"fetch_kb_raw": fk, "write_kb_raw": wk, "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "launches": len(f)}
+res = {"_correction": "FETCH_SIZE x2 (gfx950 counts 128-B fabric reads as 64 B), WRITE_SIZE as is, KB -> x1024",
+       "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 scripts/prof_update.py 3",
+       "kernels": kern}
+g8 = [v for k, v in kern.items() if "rs_ppo_grad2_kernel<8>" in k]
+g1 = [v for k, v in kern.items() if "rs_ppo_grad2_kernel<1>" in k]
+rd = [v for k, v in kern.items() if "rs_ppo_reduce_kernel" in k]
+res["grad_pass_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] for v in g8 + g1 + rd)
+for k, v in kern.items():
+    if k.startswith("rs_step_kernel<false>@grid4096"):
+        res["env_step_4096_bytes_per_launch"] = v["hbm_bytes_per_launch"]
+    if k.startswith("rs_step_kernel<false>@grid1048576"):
+        res["env_step_1048576_bytes_per_launch"] = v["hbm_bytes_per_launch"]
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in res.items() if not k.startswith("_") and k != "kernels"}))
+for k, v in kern.items():
+    print(f"{k:60s} fetch {2*v['fetch_kb_raw']/1024:9.2f} MB  write {v['write_kb_raw']/1024:9.2f} MB  x{v['launches']}")
