@@ -229,6 +229,9 @@ def main():
 
     for _ in range(args.warmup):
         one_iter(False)
+    fused = getattr(agents[0], "_fused", None)
+    if fused is not None:
+        fused.launch_events = []          # HIP events around every rs_ppo_grad launch of the timed region
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -262,14 +265,20 @@ def main():
         pmc = pmc_traffic() if N == ENVS_PER_GPU else None
         # dominant kernel of the PPO iteration: the fused loss+gradient pass (<= 40 launches per iteration), MFMA bound
         if args.collector == "fused":
-            g_ms, g_m = time_grad_pass(col)
+            evs = (fused.launch_events or []) if fused is not None else []
+            if fused is not None:
+                fused.launch_events = None
+            g_iso_ms, g_m = time_grad_pass(col)
+            g_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) if evs else g_iso_ms
             tfl = PPO_GRAD_FLOPS_PER_SAMPLE * g_m / (g_ms * 1e-3) / 1e12
             result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad2_kernel<8> + rs_ppo_grad2_kernel<1> (+ rs_ppo_reduce_kernel)",
                                   "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
                                   "traffic": pmc["grad_pass_bytes_per_launch"] if pmc else None,
                                   "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if pmc else None,
                                   "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
-                                  "avg_launch_ms": g_ms, "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
+                                  "avg_launch_ms": g_ms, "launches_timed": len(evs), "avg_launch_ms_isolated": g_iso_ms,
+                                  "timing": "HIP events on the launch stream around every rs_ppo_grad launch of the timed region",
+                                  "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
         k1 = time_step_kernel(env)
         bytes_per_launch = K1_BYTES_PER_AGENT_STEP * N * 1
         achieved = bytes_per_launch / (k1["avg_ms"] * 1e-3) / 1e9

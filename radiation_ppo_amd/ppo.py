@@ -105,6 +105,7 @@ class FusedPPOGrad:
         self.v = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)       # Adam exp_avg_sq
         self.state = torch.zeros(8, dtype=torch.float64, device=dev)          # rs_update_state (56 bytes used)
         self.state_i32 = self.state.view(torch.int32)                         # [adam_step, stopped, iters, pad, ...]
+        self.launch_events = None        # list -> every rs_ppo_grad launch is bracketed by HIP events on its stream (bench.py)
         self.views = []
         o = 0
         for p in order:
@@ -137,9 +138,16 @@ class FusedPPOGrad:
         b = _lib.RsPpoBatch(X.data_ptr(), act.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp_old.data_ptr(), w.data_ptr(),
                             X.shape[0], clip_ratio, alpha, vf_coef)
         pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
+        ev = None
+        if self.launch_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
                                         self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
                                         torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
+        if ev is not None:
+            ev[1].record()
+            self.launch_events.append(ev)
         return self.stats, self.grads
 
     def allreduce(self) -> None:
