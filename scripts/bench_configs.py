@@ -29,6 +29,8 @@ env = RadSearchVec(N, obstruction_count=-1, enforce_grid_boundaries=True, seed=S
 ag = {0: VecAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1)}
 out["config3_obstacles_8192_mlp"] = run(FusedCollector(env, ag, T, L), 6, N, T)
 del env, ag
+if len(sys.argv) > 1 and sys.argv[1] == "c3only":
+    print(json.dumps(out, indent=1)); sys.exit(0)
 # config 4 (reduced: 256 envs): 4 agents, CNN, global critic, obstacles
 N, T, L, A = 256, 120, 30, 4
 env = RadSearchVec(N, number_agents=A, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED)
