@@ -35,7 +35,7 @@ namespace {
 constexpr int CNN_NT = 192;                 // threads per workgroup (3 waves); 169 of them own a pooled cell / pixel
 constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
 constexpr int PW = 13, PC = 169;            // pooled side and cells
-constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 4;   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
+constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 6;   // (+6: see the bank map of the dW1 gather in rs_cnn_bwd_kernel)   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
                                                 // border only feeds conv1 row/column 26, which the pool drops; even stride (b64 reads)
 constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
     float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
     uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [169][8]
+    int* celloff = reinterpret_cast<int*>(ambuf + C1 * PC);           // [169] offset of a cell's 2x2 block inside a padded plane
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;
@@ -286,13 +287,21 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     v4f accw[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) accw[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-    // dW1: thread = (output channel co1, input channel c0) x cell group; 9 taps (+ db1 on the c0 == 0 threads)
-    constexpr int NCOMBO = C1 * CIN, NGRP = CNN_NT / NCOMBO;     // 48 x 4 (actor), 32 x 6 (critic)
-    float aw1[10];
+    // dW1: thread = (output channel co1, half of the input channels) x one of 12 cell groups: per cell three index reads
+    // (gradient, arg-max, cell offset) feed CG*9 window reads + FMAs (+ db1 on the first-half threads)
+    constexpr int CG = CIN / 2, NCOMBO = C1 * 2, NGRP = CNN_NT / NCOMBO, AW = CG * 9 + 1;     // 16 combos x 12 groups
+    float aw1[AW];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) aw1[k] = 0.0f;
+    for (int k = 0; k < AW; ++k) aw1[k] = 0.0f;
     const int combo = tid % NCOMBO, grp = tid / NCOMBO;
-    const int co1 = combo & 7, c0 = combo >> 3;
+    const int co1 = combo & 7, c0g = combo >> 3;
+    // Cells are walked column-major, so the 4 cells a wave gathers at once share cx and differ in cy: their window
+    // offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks, and the second channel half (3 planes = 2370 floats
+    // = +2 banks) takes the other 16 -> the 9-tap gathers are conflict-free (row-major neighbours collided 2-3 way).
+    for (int e = tid; e < PC; e += CNN_NT) {
+        const int cy = e % PW, cx = e / PW;
+        celloff[e] = (((2 * cy) * XP_RS + 2 * cx) << 8) | (cy * PW + cx);
+    }
     // MFMA operand coordinates of this lane
     const int mrow = lane & 15, mk = lane >> 4;
     int bci[5], bky[5], bkx[5], bmode[5];           // B column n = 16*tile + mrow -> (ci,ky,kx) / ones / zero
@@ -379,30 +388,23 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
                 gbuf[ci * PC + tid] = (pp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1] > 0.0f) ? g[ci] : 0.0f;
         }
         __syncthreads();
-        // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel.  Four cells in flight per
-        // trip and no branch on g == 0 (a dead cell just adds zeros) so the g -> argmax -> window -> FMA chains overlap.
+        // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel (no branch on g == 0: a dead
+        // cell adds zeros; the phase is instruction-issue bound, so the index work is shared by CG channels)
 #if !(defined(CNN_ABL) && CNN_ABL == 1)
-        for (int c = grp; c < PC; c += 4 * NGRP) {
-            float gv[4];
-            const float* base[4];
+#pragma unroll 2
+        for (int c = grp; c < PC; c += NGRP) {
+            const int tab = celloff[c], cid = tab & 255;
+            const float gv = gbuf[co1 * PC + cid];
+            const int am = ambuf[cid * C1 + co1];
+            const float* base = xp + (c0g * CG) * XP_PLANE + (tab >> 8) + (am >> 1) * XP_RS + (am & 1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cu = c + u * NGRP;
-                const bool ok = cu < PC;
-                const int cq = ok ? cu : grp;
-                gv[u] = ok ? gbuf[co1 * PC + cq] : 0.0f;
-                const int am = ambuf[cq * C1 + co1];
-                const int cy = cq / PW, cx = cq - cy * PW;
-                base[u] = xp + c0 * XP_PLANE + (2 * cy + (am >> 1)) * XP_RS + 2 * cx + (am & 1);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int j = 0; j < CG; ++j)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) aw1[ky * 3 + kx] = __builtin_fmaf(gv[u], base[u][ky * XP_RS + kx], aw1[ky * 3 + kx]);
-                aw1[9] += gv[u];
-            }
+                    for (int kx = 0; kx < 3; ++kx)
+                        aw1[j * 9 + ky * 3 + kx] = __builtin_fmaf(gv, base[j * XP_PLANE + ky * XP_RS + kx], aw1[j * 9 + ky * 3 + kx]);
+            aw1[AW - 1] += gv;
         }
 #endif
         __syncthreads();
@@ -411,10 +413,10 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     }
     // ---- workgroup reduction (fixed order) -> slab row
     __syncthreads();
-    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][10] then [3][16][80]
-    float* red2 = red + CNN_NT * 10;
+    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW] then [3][16][80]
+    float* red2 = red + CNN_NT * AW;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) red[tid * 10 + k] = aw1[k];
+    for (int k = 0; k < AW; ++k) red[tid * AW + k] = aw1[k];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
@@ -422,14 +424,20 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     __syncthreads();
     constexpr int ROW = C1 * K1 + C1 + C2 * 72 + C2;
     float* out = slab + (size_t)blockIdx.x * ROW;
-    for (int e = tid; e < NCOMBO * 10; e += CNN_NT) {
-        const int cb = e / 10, k = e - cb * 10;
+    for (int e = tid; e < C1 * K1 + C1; e += CNN_NT) {
+        int o1, cb, slot;
+        if (e < C1 * K1) {
+            o1 = e / K1;
+            const int k = e - o1 * K1, i0 = k / 9, kk = k - i0 * 9;
+            cb = o1 + 8 * (i0 / CG);
+            slot = (i0 % CG) * 9 + kk;
+        } else {
+            o1 = e - C1 * K1; cb = o1; slot = AW - 1;           // db1 lives on the first-half threads
+        }
         float sum = 0.0f;
 #pragma unroll
-        for (int gi = 0; gi < NGRP; ++gi) sum += red[(gi * NCOMBO + cb) * 10 + k];
-        const int o1 = cb & 7, i0 = cb >> 3;
-        if (k < 9) out[o1 * K1 + i0 * 9 + k] = sum;
-        else if (i0 == 0) out[C1 * K1 + o1] = sum;
+        for (int gi = 0; gi < NGRP; ++gi) sum += red[(gi * NCOMBO + cb) * AW + slot];
+        out[e] = sum;
     }
     for (int e = tid; e < C2 * 73; e += CNN_NT) {
         const int co = e / 73, n = e - co * 73;
@@ -440,8 +448,8 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
 
 inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE); }
 inline size_t bwd_lds(int cin) {
-    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC;
-    size_t red = (size_t)(CNN_NT * 10 + 3 * 16 * 80) * 4;
+    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
+    size_t red = (size_t)(CNN_NT * ((cin / 2) * 9 + 1) + 3 * 16 * 80) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
 // persistent grid: exactly as many workgroups as are resident at once (occupancy query x CU count), so no second,

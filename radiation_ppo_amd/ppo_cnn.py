@@ -26,7 +26,7 @@ class CNNAgentPPO:
     def __init__(self, id: int, map_dim=(27, 27), action_space: int = 8, train_pi_iters: int = 40, train_v_iters: int = 40,
                  actor_learning_rate: float = 3e-4, critic_learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 0.0,
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, GlobalCritic: Optional[CNNCritic] = None,
-                 GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 32768, **unused: Any):
+                 GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 524288, **unused: Any):
         self.id = id
         self.device = torch.device(device)
         self.gamma, self.lam, self.alpha = gamma, lam, alpha
