@@ -410,8 +410,9 @@ def gen_cnn():
         probs = torch.stack([actor.actor(xs_a[i]) for i in range(5)])
         vals = torch.stack([critic.forward(xs_c[i]) for i in range(5)])
     out = {"xa": xs_a.numpy(), "xc": xs_c.numpy(), "probs": probs.numpy(), "vals": vals.numpy().reshape(-1)}
-    out.update({"a_" + k: v.numpy() for k, v in actor.state_dict().items()})
-    out.update({"c_" + k: v.numpy() for k, v in critic.state_dict().items()})
+    # (the reference modules also carry unused debugging copies `step1..step7` of the layers: not saved)
+    out.update({"a_" + k: v.numpy() for k, v in actor.state_dict().items() if k.startswith("actor.")})
+    out.update({"c_" + k: v.numpy() for k, v in critic.state_dict().items() if k.startswith("critic.")})
     np.savez_compressed(os.path.join(OUT, "cnn.npz"), **out)
     print("wrote cnn.npz", [k for k in out if k.startswith(("a_", "c_"))])
 
