@@ -108,6 +108,15 @@ int rs_set_epoch_end(rs_handle* h, rs_stream_t stream);
 int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float* team, uint8_t* done,
              const rs_info* info, rs_stream_t stream);
 
+/* RadSearch.refresh_environment (rad_search_env.py:799-874): start the masked envs' episodes from SAVED parameters
+ * instead of sampling them (the evaluation harness replays its test-environment sets this way, evaluate.py:346).
+ * src_xy, det_xy [N][2] int32 (cm), intensity, bkg [N] int32; num_obs [N] + rects [N][7][4] int32 (x0,y0,x1,y1) replace
+ * the obstacle layout, or both NULL to keep the env's current one (the reference's num_obs = 0 default).  Outputs as
+ * rs_reset (the observation of the idle step the reference takes); afterwards iter_count = 1 as in the reference. */
+int rs_refresh(rs_handle* h, const uint8_t* mask, const int32_t* src_xy, const int32_t* det_xy, const int32_t* intensity,
+               const int32_t* bkg, const int32_t* num_obs, const int32_t* rects, float* obs, float* reward, float* team,
+               uint8_t* done, const rs_info* info, rs_stream_t stream);
+
 /* One lock-step of all N envs.  actions [N,A] int8 in 0..8 (-1 == idle 8).  Outputs as rs_reset.
  * done[n,a] is the env-wide latch as seen when agent a returned (rad_search_env.py:509,613). */
 int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, float* team, uint8_t* done,

@@ -645,6 +645,34 @@ class RadSearchOracle:
             self.episode += 1
         return ret
 
+    # ------------------------------------------------------------------ refresh_environment (:799-874)
+    def refresh_environment(self, src, det, intensity, bkg, rects=None):
+        """Start an episode from saved parameters.  rects=None keeps the current layout (num_obs = 0 default).
+        sp_dist is left stale exactly as the reference leaves it: step(None) copies the OLD prev_det_dist (:562)
+        before prev_det_dist is recomputed for the new geometry (:866-868)."""
+        self.epoch_end = False
+        self.done = False
+        self.iter_count = 0
+        self.rng.begin_reset(self.episode)          # a fresh draw episode, like reset (the device does the same)
+        self.t = 0
+        self.src = (int(src[0]), int(src[1]))
+        self.intensity = int(intensity)
+        self.bkg_intensity = int(bkg)
+        for agent in self.agents.values():
+            agent.reset()
+            agent.det = (int(det[0]), int(det[1]))
+            agent.detector = agent.det
+        if rects is not None:                       # :829-858
+            self.rects = [tuple(int(v) for v in r) for r in rects]
+            self.num_obs = len(self.rects)
+        self.dsrc = source_vertex_dists(self.src[0], self.src[1], self.rects)
+        ret = self.step(None)                       # :860
+        for agent in self.agents.values():          # :866-868
+            agent.prev_det_dist = shortest_path_len(self.src[0], self.src[1], agent.det[0], agent.det[1], self.rects, self.dsrc)
+        self.iter_count = 1                         # :870
+        self.episode += 1
+        return ret[0]
+
     # ------------------------------------------------------------------ take_action (:876-946)
     def _take_action(self, agent, action, proposed):
         if action is None:

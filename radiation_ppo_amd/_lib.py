@@ -63,6 +63,8 @@ SYMBOLS = [
     ("rs_set_epoch_end", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rs_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.POINTER(RsInfo), C.c_void_p]),
+    ("rs_refresh", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RsInfo), C.c_void_p]),
     ("rs_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.POINTER(RsInfo), C.c_void_p]),
     ("rs_action_uniforms", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -45,6 +45,8 @@
 struct RsParams {
     int N, A, G;                       // envs, agents, geometry groups (G = ceil(N / group))
     int obstruction_count, enforce, falloff, group;
+    int uniform_nobs;                  // > 0: every env holds exactly this many rectangles (fixed obstruction_count and no
+                                       // saved layout loaded by rs_refresh yet) -> obstacle loops are wave-uniform
     int bx0, by0, bx1, by1;            // bbox
     int sa_x0, sa_y0, sa_x1, sa_y1;    // search area (rad_search_env.py:393-420)
     int oa_lo, oa_hi;                  // observation_area
@@ -614,7 +616,7 @@ __device__ __forceinline__ void rs_load_geo(const RsParams& P, int n, bool activ
         g.r = lds_geo; g.stride = RS_WAVE; g.off = lane; g.n = no;
     }
     // a fixed obstruction_count is wave-uniform (a kernel argument): loops over obstacles become scalar loops
-    if (P.obstruction_count > 0 && active) g.n = P.obstruction_count;
+    if (P.uniform_nobs > 0 && active) g.n = P.uniform_nobs;
 }
 
 __device__ __forceinline__ void rs_copy_out(const RsParams& P, float* obs, const float* tile, const int* flags, int wave_env0) {
@@ -679,6 +681,44 @@ __device__ __forceinline__ bool rs_layout_valid(const int* lds_geo, int stride, 
         }
     }
     return true;
+}
+
+// Geodesic distance source -> every rectangle vertex (visibility graph relaxation in per-wave LDS scratch), cached
+// in P.dsrc for the episode: rs_shortest_path then needs one visibility test per candidate vertex.
+template <bool HAS_OBS>
+__device__ __forceinline__ void rs_source_geodesics(const RsParams& P, const RsGeo& g, int n, int srx, int sry,
+                                                    uint32_t* lds_adj, double* lds_d) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.N;
+    const int V = HAS_OBS ? 4 * g.n : 0;
+    for (int v = 0; v < V; ++v) {
+        int vx, vy; g.vertex(v, vx, vy);
+        lds_d[v * RS_WAVE + lane] = rs_visible(g, srx, sry, vx, vy) ? rs_dist_i(srx, sry, vx, vy) : INFINITY;
+        uint32_t m = 0;
+        for (int u = 0; u < V; ++u) {
+            if (u == v) continue;
+            int ux, uy; g.vertex(u, ux, uy);
+            if (rs_visible(g, ux, uy, vx, vy)) m |= 1u << u;
+        }
+        lds_adj[v * RS_WAVE + lane] = m;
+    }
+    bool changed = V > 0;
+    while (changed) {
+        changed = false;
+        for (int v = 0; v < V; ++v) {
+            int vx, vy; g.vertex(v, vx, vy);
+            uint32_t m = lds_adj[v * RS_WAVE + lane];
+            double dv = lds_d[v * RS_WAVE + lane];
+            for (int u = 0; u < V; ++u) {
+                if (!(m >> u & 1u)) continue;
+                int ux, uy; g.vertex(u, ux, uy);
+                double c = lds_d[u * RS_WAVE + lane] + rs_dist_i(ux, uy, vx, vy);
+                if (c < dv) { dv = c; changed = true; }
+            }
+            lds_d[v * RS_WAVE + lane] = dv;
+        }
+    }
+    for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -746,36 +786,7 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
         P.num_obs[n] = g.n;
         for (int w = 0; w < 4 * g.n; ++w) P.rect[(size_t)w * P.G + n] = lds_geo[w * RS_WAVE + lane];
     }
-    // ---- geodesic distances source -> rectangle vertices (visibility graph relaxation)
-    const int V = HAS_OBS ? 4 * g.n : 0;
-    for (int v = 0; v < V; ++v) {
-        int vx, vy; g.vertex(v, vx, vy);
-        lds_d[v * RS_WAVE + lane] = rs_visible(g, srx, sry, vx, vy) ? rs_dist_i(srx, sry, vx, vy) : INFINITY;
-        uint32_t m = 0;
-        for (int u = 0; u < V; ++u) {
-            if (u == v) continue;
-            int ux, uy; g.vertex(u, ux, uy);
-            if (rs_visible(g, ux, uy, vx, vy)) m |= 1u << u;
-        }
-        lds_adj[v * RS_WAVE + lane] = m;
-    }
-    bool changed = V > 0;
-    while (changed) {
-        changed = false;
-        for (int v = 0; v < V; ++v) {
-            int vx, vy; g.vertex(v, vx, vy);
-            uint32_t m = lds_adj[v * RS_WAVE + lane];
-            double dv = lds_d[v * RS_WAVE + lane];
-            for (int u = 0; u < V; ++u) {
-                if (!(m >> u & 1u)) continue;
-                int ux, uy; g.vertex(u, ux, uy);
-                double c = lds_d[u * RS_WAVE + lane] + rs_dist_i(ux, uy, vx, vy);
-                if (c < dv) { dv = c; changed = true; }
-            }
-            lds_d[v * RS_WAVE + lane] = dv;
-        }
-    }
-    for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + lane];
+    rs_source_geodesics<HAS_OBS>(P, g, n, srx, sry, lds_adj, lds_d);
     double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
     // ---- state write (Agent.reset :292-301, reset :736-742, :771-776)
     P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = intensity; P.bkg[n] = bkg;
@@ -792,4 +803,60 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
         rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
         P.iter_count[n] = 0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RadSearch.refresh_environment for env n (rad_search_env.py:799-874): start an episode from SAVED parameters
+// (source, detector start, intensity, background, optionally the obstacle rectangles) instead of sampling them --
+// the evaluation harness replays its test-environment sets this way (evaluate.py:346).
+// As in the reference, sp_dist is left STALE by this call: its step(None) copies the previous episode's
+// prev_det_dist into sp_dist (:562) and only afterwards is prev_det_dist recomputed for the new geometry (:866-868),
+// so until the first move that succeeds a stalled step is priced with the old distance.
+struct RsRefresh {
+    const int32_t* src;        // [N][2]
+    const int32_t* det;        // [N][2]
+    const int32_t* intensity;  // [N]
+    const int32_t* bkg;        // [N]
+    const int32_t* num_obs;    // [N] or nullptr: keep the env's current layout (refresh_environment's num_obs = 0 default)
+    const int32_t* rects;      // [N][RS_MAX_OBS][4] (x0,y0,x1,y1) when num_obs is given
+};
+
+template <bool HAS_OBS>
+__device__ __forceinline__ void rs_env_refresh_lane(const RsParams& P, RsGeo& g, int n, const RsRefresh& R, int* lds_geo,
+                                                    uint32_t* lds_adj, double* lds_d, float* obs_row, const RsOut& O) {
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, A = P.A;
+    const uint32_t episode = P.episode[n];
+    if (HAS_OBS && P.group == 1) {
+        g.r = lds_geo; g.stride = RS_WAVE; g.off = lane;
+        if (R.num_obs) {
+            int num = R.num_obs[n];
+            num = num < 0 ? 0 : (num > RS_MAX_OBS ? RS_MAX_OBS : num);
+            for (int w = 0; w < 4 * num; ++w) {
+                const int v = R.rects[(size_t)n * RS_MAX_OBS * 4 + w];
+                lds_geo[w * RS_WAVE + lane] = v;
+                P.rect[(size_t)w * P.G + n] = v;
+            }
+            P.num_obs[n] = num;
+            g.n = num;
+        } else {
+            g.n = P.num_obs[n];
+            for (int w = 0; w < 4 * g.n; ++w) lds_geo[w * RS_WAVE + lane] = P.rect[(size_t)w * P.G + n];
+        }
+    }
+    P.epoch_end[n] = 0;                                                   // :810
+    const int srx = R.src[2 * n], sry = R.src[2 * n + 1], dtx = R.det[2 * n], dty = R.det[2 * n + 1];
+    rs_source_geodesics<HAS_OBS>(P, g, n, srx, sry, lds_adj, lds_d);
+    const double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
+    P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = R.intensity[n]; P.bkg[n] = R.bkg[n];
+    P.done[n] = 0; P.iter_count[n] = 0; P.tstep[n] = 0;                   // :811-812
+    for (int a = 0; a < A; ++a) {                                         // Agent.reset + det_coords (:823-826)
+        size_t ia = (size_t)a * N + n;
+        P.ax[ia] = dtx; P.ay[ia] = dty; P.sp[ia] = P.prev[ia]; P.prev[ia] = prev; P.oobc[ia] = 0; P.aflags[ia] = 0;
+    }
+    RsOut o = O;
+    o.obs_row = obs_row;
+    P.episode[n] = episode + 1;                                           // a fresh Philox episode, as after reset
+    rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);     // :860
+    P.iter_count[n] = 1;                                                  // :870
 }

@@ -88,6 +88,27 @@ __global__ void __launch_bounds__(64) rs_reset_kernel(RsParams P, const uint8_t*
     rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);
 }
 
+// K2b: RadSearch.refresh_environment for the masked envs (rad_search_env.py:799-874)
+template <bool HAS_OBS>
+__global__ void __launch_bounds__(64) rs_refresh_kernel(RsParams P, const uint8_t* __restrict__ mask, RsRefresh R, float* obs, RsOut O) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool has_obs = HAS_OBS;
+    int* lds_geo = reinterpret_cast<int*>(smem);
+    uint32_t* lds_adj = reinterpret_cast<uint32_t*>(smem + RS_MAX_VERT * RS_WAVE * 4);
+    double* lds_d = reinterpret_cast<double*>(smem + 2 * RS_MAX_VERT * RS_WAVE * 4);
+    float* tile = reinterpret_cast<float*>(smem + (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0));
+    int* flags = reinterpret_cast<int*>(tile + RS_WAVE * rs_tile_stride(P.A));
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = n < P.N && (mask == nullptr || mask[n] != 0);
+    RsGeo g{lds_geo, 0, 0, 0};
+    flags[lane] = active ? 1 : 0;
+    __syncthreads();
+    if (active) rs_env_refresh_lane<HAS_OBS>(P, g, n, R, lds_geo, lds_adj, lds_d, tile + lane * rs_tile_stride(P.A), O);
+    __syncthreads();
+    rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);
+}
+
 __global__ void __launch_bounds__(64) rs_action_uniform_kernel(RsParams P, float* __restrict__ u) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= P.N) return;
@@ -185,6 +206,7 @@ static size_t carve(const rs_config* c, unsigned char* base, rs_handle* h) {
     if (h) {
         P.N = N; P.A = A; P.G = G;
         P.obstruction_count = c->obstruction_count; P.enforce = c->enforce_grid_boundaries ? 1 : 0;
+        P.uniform_nobs = c->obstruction_count > 0 ? c->obstruction_count : 0;
         P.falloff = c->falloff ? 1 : 0; P.group = c->geom_group_size;
         P.bx0 = c->bbox[0]; P.by0 = c->bbox[1]; P.bx1 = c->bbox[2]; P.by1 = c->bbox[3];
         P.oa_lo = c->observation_area[0]; P.oa_hi = c->observation_area[1];
@@ -285,6 +307,22 @@ int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float
     size_t lds = tile_bytes(P.A) + (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
     if (has_obs) hipLaunchKernelGGL(rs_reset_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_reset_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_refresh(rs_handle* h, const uint8_t* mask, const int32_t* src_xy, const int32_t* det_xy, const int32_t* intensity,
+               const int32_t* bkg, const int32_t* num_obs, const int32_t* rects, float* obs, float* reward, float* team,
+               uint8_t* done, const rs_info* info, rs_stream_t stream) {
+    if (!h || !src_xy || !det_xy || !intensity || !bkg || ((num_obs == nullptr) != (rects == nullptr))) return RS_ERR_INVALID_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RsParams& P = h->P;
+    const bool has_obs = P.obstruction_count != 0;
+    if (num_obs && (!has_obs || P.group > 1)) return RS_ERR_UNSUPPORTED;     // layouts are per env; obstacle-free handles hold none
+    if (num_obs) h->P.uniform_nobs = 0;                  // saved layouts may hold any number of rectangles from now on
+    RsRefresh R{src_xy, det_xy, intensity, bkg, num_obs, rects};
+    size_t lds = tile_bytes(P.A) + (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
+    if (has_obs) hipLaunchKernelGGL(rs_refresh_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, R, obs, make_out(reward, team, done, info));
+    else hipLaunchKernelGGL(rs_refresh_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, R, obs, make_out(reward, team, done, info));
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

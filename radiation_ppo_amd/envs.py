@@ -141,6 +141,29 @@ class RadSearchVec:
                    "rs_step")
         return self._outs()
 
+    def refresh(self, src_xy: torch.Tensor, det_xy: torch.Tensor, intensity: torch.Tensor, bkg: torch.Tensor,
+                num_obs: Optional[torch.Tensor] = None, rects: Optional[torch.Tensor] = None,
+                mask: Optional[torch.Tensor] = None):
+        """RadSearch.refresh_environment (rad_search_env.py:799-874) for the masked envs: episodes start from saved
+        parameters.  src_xy, det_xy [N,2] int32; intensity, bkg [N] int32; num_obs [N] + rects [N,7,4] int32 (x0,y0,x1,y1)
+        replace the obstacle layouts (both None: keep them)."""
+        N = self.num_envs
+        for t, shape in ((src_xy, (N, 2)), (det_xy, (N, 2)), (intensity, (N,)), (bkg, (N,))):
+            assert t.dtype == torch.int32 and tuple(t.shape) == shape and t.is_contiguous() and t.device == self.device
+        if num_obs is not None:
+            assert rects is not None and num_obs.dtype == torch.int32 and rects.dtype == torch.int32
+            assert tuple(num_obs.shape) == (N,) and tuple(rects.shape) == (N, _lib.RS_MAX_OBS, 4) and rects.is_contiguous()
+        if mask is not None:
+            if mask.dtype == torch.bool:
+                mask = mask.to(torch.uint8)
+            assert mask.dtype == torch.uint8 and mask.numel() == N and mask.is_contiguous()
+        self._refresh_keepalive = (src_xy, det_xy, intensity, bkg, num_obs, rects, mask)
+        _lib.check(self.lib.rs_refresh(self._h, _ptr(mask), src_xy.data_ptr(), det_xy.data_ptr(), intensity.data_ptr(),
+                                       bkg.data_ptr(), _ptr(num_obs), _ptr(rects), self.obs.data_ptr(), self.reward.data_ptr(),
+                                       self.team.data_ptr(), self.done.data_ptr(), C.byref(self._info), self._stream()),
+                   "rs_refresh")
+        return self._outs()
+
     def action_uniforms(self, out: torch.Tensor) -> torch.Tensor:
         """u[N,A] in [0,1) for inverse-CDF action sampling, from each env's own Philox stream (rs_action_uniforms)."""
         assert out.dtype == torch.float32 and out.numel() == self.num_envs * self.number_agents and out.is_contiguous()
@@ -305,4 +328,35 @@ class RadSearch:
         raise NotImplementedError("rendering (rad_search_env.py:1308-1762) is outside the hot path")
 
     def refresh_environment(self, env_dict, id, num_obs=0):
-        raise NotImplementedError("evaluation harness support (rad_search_env.py:799-874) is SURVEY.md section 8 row f3")
+        """rad_search_env.py:799-874: load saved episode parameters `env_dict["env_<id>"] = (src_coords, det_coords,
+        intensity, bkg_intensity[, obstacles])` (format of algos/test_environment/eval/test_env_gen.py:13-24; each
+        obstacle is `[array of its 4 corner points]`) and return the observation of the idle step."""
+        e = env_dict["env_" + str(id)]
+        dev = self._vec.device
+
+        def grid(p):
+            q = [float(p[0]), float(p[1])]
+            if q[0] != int(q[0]) or q[1] != int(q[1]):
+                raise ValueError("saved coordinates must lie on the 1 cm lattice the environment samples from")
+            return [int(q[0]), int(q[1])]
+        src = torch.tensor([grid(e[0])], dtype=torch.int32, device=dev)
+        det = torch.tensor([grid(e[1])], dtype=torch.int32, device=dev)
+        inten = torch.tensor([int(e[2])], dtype=torch.int32, device=dev)
+        bkg = torch.tensor([int(e[3])], dtype=torch.int32, device=dev)
+        nob = rects = None
+        if num_obs > 0:                                                   # :829-858 (the stored list decides the count)
+            obstacles = e[4]
+            if len(obstacles) > _lib.RS_MAX_OBS:
+                raise ValueError("more than 7 obstructions")
+            r = np.zeros((1, _lib.RS_MAX_OBS, 4), dtype=np.int32)
+            for i, ob in enumerate(obstacles):
+                pts = np.asarray(ob[0], dtype=np.float64)
+                xs, ys = pts[:, 0], pts[:, 1]
+                if not (np.all(xs == np.round(xs)) and np.all(ys == np.round(ys))):
+                    raise ValueError("saved obstruction corners must lie on the 1 cm lattice")
+                r[0, i] = (int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max()))
+            nob = torch.tensor([len(obstacles)], dtype=torch.int32, device=dev)
+            rects = torch.from_numpy(r).to(dev)
+        self.epoch_end = False
+        observation, _, _, _ = self._tuple(self._vec.refresh(src, det, inten, bkg, nob, rects))
+        return observation

@@ -693,11 +693,57 @@ def gen_cnn_loss():
     print("wrote cnn_loss.npz", float(out["pi_loss"]), float(out["kl"]), float(out["clip_fraction"]), float(out["critic_loss"]))
 
 
+def gen_refresh():
+    """refresh_environment (rad_search_env.py:799-874), obstacle-free: saved (source, detector, intensity, background)
+    tuples in the format of algos/test_environment/eval/test_env_gen.py:13-24 are loaded into the reference env, followed
+    by scripted steps (incl. a first step that runs into the wall, which is priced with the STALE sp_dist)."""
+    from gym_rad_search.envs.rad_search_env import RadSearch
+    import json
+    out = {}
+    for name, A, enforce in (("a1", 1, True), ("a2", 2, True), ("a1_free", 1, False)):
+        rec = RecordingGenerator(21)
+        env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0, enforce_grid_boundaries=enforce)
+        rows = []
+        script = np.random.default_rng(5 + A)
+        env_dict = {"env_0": (np.array([1500.0, 700.0]), np.array([205.0, 1900.0]), 4321000, 37),
+                    "env_1": (np.array([300.0, 2100.0]), np.array([2100.0, 400.0]), 9000123, 12),
+                    "env_2": (np.array([1000.0, 1000.0]), np.array([2199.0, 2199.0]), 1000000, 50)}
+        for eid in (0, 1, 2, 1):
+            ls = len(rec.log)
+            obs = env.refresh_environment(env_dict, eid)
+            rows.append(dict(kind="refresh", id=eid, obs={str(i): np.asarray(obs[i], dtype=np.float64).tolist() for i in range(A)},
+                             draws=rec.log[ls:], **_snapshot(env, A)))
+            for t in range(14):
+                if t == 0:
+                    acts = {i: 0 for i in range(A)}                 # into the left wall for env_0 (x = 205 - 100 < 200... outside)
+                elif t < 6:
+                    acts = {i: _greedy_action(env, i) if i == 0 else int(script.integers(0, 9)) for i in range(A)}
+                else:
+                    acts = {i: int(script.integers(0, 9)) for i in range(A)}
+                ls = len(rec.log)
+                o, r, d, info = env.step(acts)
+                rows.append(dict(kind="step", actions={str(k): int(v) for k, v in acts.items()},
+                                 obs={str(i): np.asarray(o[i], dtype=np.float64).tolist() for i in range(A)},
+                                 reward={str(i): float(r["individual_reward"][i]) for i in range(A)},
+                                 done_ret={str(i): bool(d[i]) for i in range(A)}, draws=rec.log[ls:], **_snapshot(env, A)))
+                if env.done:
+                    break
+        out[name] = dict(A=A, enforce=enforce, seed=21, init_draws=[], rows=rows,
+                         env_dict={k: [np.asarray(v[0]).tolist(), np.asarray(v[1]).tolist(), int(v[2]), int(v[3])] for k, v in env_dict.items()})
+        # draws consumed by the constructor's reset come first in rec.log: keep them so a replay starts identically
+        n_init = len(rec.log) - sum(len(r["draws"]) for r in rows)
+        out[name]["init_draws"] = rec.log[:n_init]
+        print(name, len(rows), "rows")
+    with open(os.path.join(OUT, "refresh.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote refresh.json")
+
+
 if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss"]
+    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss", "refresh"]
     if "env" in which:
         gen_env_scenarios()
     if "gae" in which:
@@ -718,3 +764,5 @@ if __name__ == "__main__":
         gen_loss()
     if "cnnloss" in which:
         gen_cnn_loss()
+    if "refresh" in which:
+        gen_refresh()

@@ -254,3 +254,87 @@ def test_nested_layout_is_rejected_like_world_is_valid(A, base, N):
     rectangle, where no path exists and the reward is -inf."""
     refs = _run(N=N, A=A, obst=-1, enforce=True, steps=40, base=base)
     assert sum(e.invalid_layouts for e in refs) >= 2
+
+
+@pytest.mark.parametrize("A,with_rects", [(1, False), (2, False), (1, True), (3, True)])
+def test_refresh_environment_matches_oracle(A, with_rects):
+    """rs_refresh (RadSearch.refresh_environment, rad_search_env.py:799-874): saved source / detector / intensity /
+    background (and obstacle rectangles) loaded into running envs, then stepped, bit-exact against the oracle --
+    including the stale sp_dist the reference carries over and iter_count = 1."""
+    N, obst = 48, (3 if with_rects else 0)
+    vec, specs, _ = _make(N, A, obst, True)
+    refs = [RadSearchOracle(PhiloxDraws(SEED, n), number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True)
+            for n, _ in specs]
+    vec.reset()
+    rng = np.random.default_rng(11)
+    for t in range(7):                                   # leave the envs mid-episode with some history
+        acts = rng.integers(0, 9, size=(N, A)).astype(np.int8)
+        vec.step(torch.from_numpy(acts).cuda())
+        for n, e in enumerate(refs):
+            e.step({a: int(acts[n, a]) for a in range(A)})
+    for rnd in range(3):
+        mask = rng.random(N) < 0.7
+        src = rng.integers(200, 2200, size=(N, 2)).astype(np.int32)
+        det = rng.integers(200, 2200, size=(N, 2)).astype(np.int32)
+        det[0] = (205, 1900)                             # first step (action 0) runs into the left wall: stale sp_dist is used
+        inten = rng.integers(1_000_000, 10_000_000, size=N).astype(np.int32)
+        bkg = rng.integers(10, 51, size=N).astype(np.int32)
+        nob = rects = None
+        if with_rects:
+            nob = rng.integers(0, 4, size=N).astype(np.int32)
+            rects = np.zeros((N, 7, 4), dtype=np.int32)
+            for n in range(N):
+                for i in range(nob[n]):                  # disjoint columns, away from the sampled points' lattice rows
+                    x0 = 300 + 600 * i + int(rng.integers(0, 50))
+                    y0 = int(rng.integers(300, 1500))
+                    rects[n, i] = (x0, y0, x0 + int(rng.integers(200, 400)), y0 + int(rng.integers(200, 500)))
+                for p in (src, det):                     # keep the saved points out of the rectangles, as saved sets are
+                    while any(rects[n, i, 0] <= p[n, 0] <= rects[n, i, 2] and rects[n, i, 1] <= p[n, 1] <= rects[n, i, 3]
+                              for i in range(nob[n])):
+                        p[n] = rng.integers(200, 2200, size=2)
+        dev = lambda a: None if a is None else torch.from_numpy(a).cuda()
+        outs = vec.refresh(dev(src), dev(det), dev(inten), dev(bkg), dev(nob), dev(rects), mask=torch.from_numpy(mask.astype(np.uint8)).cuda())
+        rets = []
+        for n, e in enumerate(refs):
+            if not mask[n]:
+                rets.append(None)
+                continue
+            o = e.refresh_environment(src[n], det[n], inten[n], bkg[n], None if rects is None else rects[n, :nob[n]])
+            rets.append(o)
+        torch.cuda.synchronize()
+        obs = outs[0].cpu().numpy()
+        it = vec.state("iter_count").cpu().numpy()[0]
+        sp, prev = vec.state("sp").cpu().numpy(), vec.state("prev").cpu().numpy()
+        for n, e in enumerate(refs):
+            if rets[n] is None:
+                continue
+            assert it[n] == 1 == e.iter_count
+            for a in range(A):
+                assert np.array_equal(obs[n, a], np.asarray(rets[n][a], dtype=np.float64).astype(np.float32)), (rnd, n, a)
+                assert sp[a, n] == e.agents[a].sp_dist and prev[a, n] == e.agents[a].prev_det_dist, (rnd, n, a)
+        for t in range(6):
+            acts = rng.integers(0, 9, size=(N, A)).astype(np.int8)
+            if t == 0:
+                acts[:, :] = 0
+            o2 = vec.step(torch.from_numpy(acts).cuda())
+            r2 = [e.step({a: int(acts[n, a]) for a in range(A)}) for n, e in enumerate(refs)]
+            torch.cuda.synchronize()
+            _compare(vec, o2, refs, r2, f"refresh{rnd}.step{t}")
+    assert vec.error_flags() == 0 and all(e.err == 0 for e in refs)
+
+
+def test_adapter_refresh_environment_reads_saved_env_dicts():
+    """The gym-style adapter takes the saved-set format of algos/test_environment/eval/test_env_gen.py:13-24."""
+    from radiation_ppo_amd.envs import RadSearch
+    env = RadSearch(number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=5)
+    corners = lambda x0, y0, x1, y1: [np.array([[x0, y0], [x0, y1], [x1, y1], [x1, y0]], dtype=np.float64)]
+    d = {"env_3": (np.array([1500.0, 700.0]), np.array([400.0, 1900.0]), 4321000, 37,
+                   [corners(800, 900, 1100, 1300), corners(1600, 1500, 1900, 1800)])}
+    obs = env.refresh_environment(d, 3, num_obs=2)
+    assert env.src_coords == (1500.0, 700.0) and env.intensity == 4321000 and env.bkg_intensity == 37
+    assert env.num_obs == 2 and env.iter_count == 1
+    assert obs[0].shape == (11,) and abs(obs[0][1] - 400 / 2200) < 1e-7 and abs(obs[0][2] - 1900 / 2200) < 1e-7
+    o, r, dn, info = env.step({0: 4})
+    assert abs(o[0][1] - 500 / 2200) < 1e-7
+    with pytest.raises(ValueError):
+        env.refresh_environment({"env_0": (np.array([1500.5, 700.0]), np.array([400.0, 1900.0]), 1, 1)}, 0)
