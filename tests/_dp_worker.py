@@ -8,6 +8,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, total_envs = sys.argv[1], int(sys.argv[2])
+mode = sys.argv[3] if len(sys.argv) > 3 else "ff"
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 torch.cuda.set_device(0)
 if world > 1:
@@ -15,6 +16,31 @@ if world > 1:
 from radiation_ppo_amd.envs import RadSearchVec                      # noqa: E402
 from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO        # noqa: E402
 
+if mode == "cnn":
+    # BASELINE config 5 in miniature: multi-agent RAD-TEAM (CNN actors, global critic, obstacles) sharded over ranks
+    from radiation_ppo_amd.maps import CNNCritic                      # noqa: E402
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector   # noqa: E402
+    N, T, L, A = total_envs // world, 24, 8, 2
+    torch.manual_seed(4321)
+    env = RadSearchVec(N, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)
+    gc = CNNCritic().cuda()
+    gco = torch.optim.Adam(gc.parameters(), lr=1e-3)
+    agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=3, train_v_iters=3,
+                             actor_learning_rate=3e-3) for i in range(A)}
+    for ag in agents.values():
+        ag.sync_params()
+    col = CNNCollector(env, agents, T, L, True)
+    col.collect()
+    res = col.update()
+    if rank == 0:
+        flat = torch.cat([p.detach().reshape(-1) for ag in agents.values() for p in ag.pi.parameters()]
+                         + [p.detach().reshape(-1) for p in gc.parameters()]).cpu()
+        torch.save({"params": flat, "kl": res[0].kl_divergence, "loss": res[0].loss_policy, "stop": res[0].stop_iteration,
+                    "entropy": res[0].Entropy, "loss_critic": res[0].loss_critic}, out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0)
 N, T, L = total_envs // world, 48, 12
 torch.manual_seed(1234)                                              # same initial policy on every rank / world size
 env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)

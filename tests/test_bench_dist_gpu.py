@@ -45,3 +45,22 @@ def test_data_parallel_equals_single_process(tmp_path):
     assert a["stop"] == b["stop"]
     assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["entropy"] - b["entropy"]) < 1e-5
     assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=2e-5), float((a["params"] - b["params"]).abs().max())
+
+
+def test_data_parallel_cnn_equals_single_process(tmp_path):
+    """The same for BASELINE config 5 in miniature (multi-agent RAD-TEAM: CNN actors, shared global critic updated by
+    agent 0, obstacles): 2 ranks x 8 envs == 1 process x 16 envs after one PPO iteration."""
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "_dp_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r1 = subprocess.run([sys.executable, worker, one, "16", "cnn"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29751", worker, two, "16", "cnn"], cwd=ROOT, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = torch.load(one), torch.load(two)
+    assert a["stop"] == b["stop"]
+    assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["loss_critic"] - b["loss_critic"]) < 1e-5
+    assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=3e-5), float((a["params"] - b["params"]).abs().max())
