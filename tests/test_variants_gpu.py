@@ -1,0 +1,19 @@
+"""The A/B kernel variants kept behind RS_GRAD_V=1 / RS_ROLLOUT_V=1 (64-sample-per-wave gradient kernel, 64-env-per-wave
+rollout) must stay correct: the fused-path tests are re-run in a child process with the toggles set."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_v1_kernel_variants_pass_the_fused_path_tests():
+    env = dict(os.environ, RS_GRAD_V="1", RS_ROLLOUT_V="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ppo_gpu.py"), "-m", "gpu", "-x", "-q", "-k",
+           "fused or device_side or reference_update_rada2c", "-p", "no:cacheprovider"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
