@@ -32,7 +32,12 @@ namespace {
 #ifndef CNN_BWD_PREFETCH
 #define CNN_BWD_PREFETCH 1
 #endif
-constexpr int CNN_NT = 192;                 // threads per workgroup (3 waves); 169 of them own a pooled cell / pixel
+constexpr int CNN_NT = 192;                 // forward: 3 waves per workgroup; 169 threads own a pooled cell / pixel
+#ifndef CNN_NTB
+#define CNN_NTB 256
+#endif
+constexpr int CNN_NT_BWD = CNN_NTB;         // backward: a 4th wave that owns no pixel shares the staging, the dW2 MFMA steps and
+                                            // the dW1 gathers -- the kernel is wait-bound (56 % of its wave cycles parked), not VALU-bound
 constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
 constexpr int PW = 13, PC = 169;            // pooled side and cells
 constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 6;   // (+6: see the bank map of the dW1 gather in rs_cnn_bwd_kernel)   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
@@ -82,18 +87,19 @@ struct CnnIn {
 
 // ---- one sample's inputs travel HBM -> registers -> LDS; the registers of sample s+grid are filled while sample s
 // is being computed (software prefetch), so the per-image memory latency is off the critical path
-constexpr int MAPS_PER_THREAD = (4 * MAPC + CNN_NT - 1) / CNN_NT;     // 16
+template <int NT>
 struct CnnFetch {
-    float m[MAPS_PER_THREAD];
+    static constexpr int PER_THREAD = (4 * MAPC + NT - 1) / NT;         // 16 (NT = 192) / 12 (NT = 256)
+    float m[PER_THREAD];
     int loc, pc;
 };
 
-template <int CIN>
-__device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch& f) {
+template <int CIN, int NT>
+__device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch<NT>& f) {
     const float* src = in.maps + (size_t)s * 4 * MAPC;
 #pragma unroll
-    for (int i = 0; i < MAPS_PER_THREAD; ++i) {
-        const int e = threadIdx.x + i * CNN_NT;
+    for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
+        const int e = threadIdx.x + i * NT;
         f.m[i] = (e < 4 * MAPC) ? src[e] : 0.0f;
     }
     f.loc = -1; f.pc = -1;
@@ -103,12 +109,12 @@ __device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch
     }
 }
 
-template <int CIN>
-__device__ __forceinline__ void cnn_stage(const CnnFetch& f, float* xp) {
+template <int CIN, int NT>
+__device__ __forceinline__ void cnn_stage(const CnnFetch<NT>& f, float* xp) {
     constexpr int CH0 = (CIN == 6) ? 2 : 0;
 #pragma unroll
-    for (int i = 0; i < MAPS_PER_THREAD; ++i) {
-        const int e = threadIdx.x + i * CNN_NT;
+    for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
+        const int e = threadIdx.x + i * NT;
         if (e < 4 * MAPC) {
             const int m = e / MAPC, q = e - m * MAPC;
             const int r = q / MAPW, c = q - r * MAPW;
@@ -161,14 +167,14 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
-    CnnFetch f;
-    if ((long long)blockIdx.x < in.S) cnn_fetch<CIN>(in, blockIdx.x, f);
+    CnnFetch<CNN_NT> f;
+    if ((long long)blockIdx.x < in.S) cnn_fetch<CIN, CNN_NT>(in, blockIdx.x, f);
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
         const int loc = f.loc, pc = f.pc;
-        cnn_stage<CIN>(f, xp);
+        cnn_stage<CIN, CNN_NT>(f, xp);
         __syncthreads();
         cnn_set_onehots<CIN>(xp, loc, pc);
-        if (s + gridDim.x < in.S) cnn_fetch<CIN>(in, s + gridDim.x, f);      // next sample: in flight during the compute
+        if (s + gridDim.x < in.S) cnn_fetch<CIN, CNN_NT>(in, s + gridDim.x, f);      // next sample: in flight during the compute
         __syncthreads();
         if (own) {
             // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const f
 // K10 backward: dL/d(a2) -> per-workgroup partial sums of dW1, db1, dW2, db2 (slab row layout:
 // [dW1 8*CIN*9 | db1 8 | dW2 16*72 | db2 16], torch weight order).
 template <int CIN>
-__global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ wt, const float* __restrict__ da2,
+__global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn in, const float* __restrict__ wt, const float* __restrict__ da2,
                                                             const uint16_t* __restrict__ relu_mask, const float* __restrict__ p1g,
                                                             const uint8_t* __restrict__ amax, float* __restrict__ slab) {
     extern __shared__ __align__(16) float smem[];
@@ -279,7 +285,8 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     int* celloff = reinterpret_cast<int*>(ambuf + C1 * PC);           // [169] offset of a cell's 2x2 block inside a padded plane
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;
+    constexpr int NWAVE = CNN_NT_BWD / 64;
+    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     for (int t = 0; t < 5; ++t) accw[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     // dW1: thread = (output channel co1, half of the input channels) x one of 12 cell groups: per cell three index reads
     // (gradient, arg-max, cell offset) feed CG*9 window reads + FMAs (+ db1 on the first-half threads)
-    constexpr int CG = CIN / 2, NCOMBO = C1 * 2, NGRP = CNN_NT / NCOMBO, AW = CG * 9 + 1;     // 16 combos x 12 groups
+    constexpr int CG = CIN / 2, NCOMBO = C1 * 2, NGRP = CNN_NT_BWD / NCOMBO, AW = CG * 9 + 1;     // 16 combos x (threads / 16) groups
     float aw1[AW];
 #pragma unroll
     for (int k = 0; k < AW; ++k) aw1[k] = 0.0f;
@@ -298,7 +305,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     // Cells are walked column-major, so the 4 cells a wave gathers at once share cx and differ in cy: their window
     // offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks, and the second channel half (3 planes = 2370 floats
     // = +2 banks) takes the other 16 -> the 9-tap gathers are conflict-free (row-major neighbours collided 2-3 way).
-    for (int e = tid; e < PC; e += CNN_NT) {
+    for (int e = tid; e < PC; e += CNN_NT_BWD) {
         const int cy = e % PW, cx = e / PW;
         celloff[e] = (((2 * cy) * XP_RS + 2 * cx) << 8) | (cy * PW + cx);
     }
@@ -312,7 +319,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
         const int nn = (n < 72) ? n : 0;
         bci[t] = nn / 9; bky[t] = (nn % 9) / 3; bkx[t] = nn % 3;
     }
-    CnnFetch f;
+    CnnFetch<CNN_NT_BWD> f;
     v4f fp1a = (v4f){0.f, 0.f, 0.f, 0.f}, fp1b = fp1a;
     float fda2[C2];
     uint2 fam = make_uint2(0u, 0u);
@@ -327,11 +334,11 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
             for (int co = 0; co < C2; ++co) fda2[co] = da2[(size_t)s * FLAT + co * PC + tid];
         }
     };
-    if ((long long)blockIdx.x < in.S) { cnn_fetch<CIN>(in, blockIdx.x, f); if (CNN_BWD_PREFETCH) fetch_acts(blockIdx.x); }
+    if ((long long)blockIdx.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, blockIdx.x, f); if (CNN_BWD_PREFETCH) fetch_acts(blockIdx.x); }
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
         const int loc = f.loc, pc = f.pc;
         if (!CNN_BWD_PREFETCH) fetch_acts(s);
-        cnn_stage<CIN>(f, xp);
+        cnn_stage<CIN, CNN_NT_BWD>(f, xp);
         if (own) {
 #pragma unroll
             for (int co = 0; co < 4; ++co) {
@@ -345,11 +352,11 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
         }
         __syncthreads();
         cnn_set_onehots<CIN>(xp, loc, pc);
-        if (s + gridDim.x < in.S) { cnn_fetch<CIN>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
+        if (s + gridDim.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
         __syncthreads();
         // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
 #if !(defined(CNN_ABL) && CNN_ABL == 3)
-        for (int st = wave; st < 43; st += 3) {
+        for (int st = wave; st < 43; st += NWAVE) {
             const int pxl = 4 * st + mk;
             const bool ok = pxl < PC;
             const int pq = ok ? pxl : (PC - 1);
@@ -413,8 +420,8 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     }
     // ---- workgroup reduction (fixed order) -> slab row
     __syncthreads();
-    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW] then [3][16][80]
-    float* red2 = red + CNN_NT * AW;
+    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW] then [NWAVE][16][80]
+    float* red2 = red + CNN_NT_BWD * AW;
 #pragma unroll
     for (int k = 0; k < AW; ++k) red[tid * AW + k] = aw1[k];
 #pragma unroll
@@ -424,7 +431,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
     __syncthreads();
     constexpr int ROW = C1 * K1 + C1 + C2 * 72 + C2;
     float* out = slab + (size_t)blockIdx.x * ROW;
-    for (int e = tid; e < C1 * K1 + C1; e += CNN_NT) {
+    for (int e = tid; e < C1 * K1 + C1; e += CNN_NT_BWD) {
         int o1, cb, slot;
         if (e < C1 * K1) {
             o1 = e / K1;
@@ -439,9 +446,11 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
         for (int gi = 0; gi < NGRP; ++gi) sum += red[(gi * NCOMBO + cb) * AW + slot];
         out[e] = sum;
     }
-    for (int e = tid; e < C2 * 73; e += CNN_NT) {
+    for (int e = tid; e < C2 * 73; e += CNN_NT_BWD) {
         const int co = e / 73, n = e - co * 73;
-        const float sum = red2[(0 * 16 + co) * 80 + n] + red2[(1 * 16 + co) * 80 + n] + red2[(2 * 16 + co) * 80 + n];
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) sum += red2[(w * 16 + co) * 80 + n];
         if (n < 72) out[C1 * K1 + C1 + co * 72 + n] = sum; else out[C1 * K1 + C1 + C2 * 72 + co] = sum;
     }
 }
@@ -449,17 +458,17 @@ __global__ void __launch_bounds__(CNN_NT, CNN_BWD_WAVES) rs_cnn_bwd_kernel(CnnIn
 inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE); }
 inline size_t bwd_lds(int cin) {
     size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
-    size_t red = (size_t)(CNN_NT * ((cin / 2) * 9 + 1) + 3 * 16 * 80) * 4;
+    size_t red = (size_t)(CNN_NT_BWD * ((cin / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
 // persistent grid: exactly as many workgroups as are resident at once (occupancy query x CU count), so no second,
 // half-empty round of workgroups trails the first; each workgroup strides over the batch
 template <typename K>
-inline int cnn_grid(K kernel, size_t lds, long long S) {
+inline int cnn_grid(K kernel, int threads, size_t lds, long long S) {
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CNN_NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const long long cap = (long long)cus * per_cu;
     return (int)(S < cap ? S : cap);
 }
@@ -470,7 +479,7 @@ extern "C" {
 
 int32_t rs_cnn_trunk_slab_row(int32_t in_channels) { return C1 * in_channels * 9 + C1 + C2 * 72 + C2; }
 int32_t rs_cnn_trunk_slab_rows(int64_t num_samples, int32_t in_channels) {
-    return in_channels == 6 ? cnn_grid(rs_cnn_bwd_kernel<6>, bwd_lds(6), num_samples) : cnn_grid(rs_cnn_bwd_kernel<4>, bwd_lds(4), num_samples);
+    return in_channels == 6 ? cnn_grid(rs_cnn_bwd_kernel<6>, CNN_NT_BWD, bwd_lds(6), num_samples) : cnn_grid(rs_cnn_bwd_kernel<4>, CNN_NT_BWD, bwd_lds(4), num_samples);
 }
 int32_t rs_cnn_trunk_scratch_floats(int32_t in_channels) { return WT_TOTAL(in_channels); }
 
@@ -485,9 +494,9 @@ int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t*
     hipStream_t s = (hipStream_t)stream;
     const int cin = agent >= 0 ? 6 : 4;
     hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, w1, b1, w2, b2, wscratch);
-    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, fwd_lds(6), num_samples)), dim3(CNN_NT),
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, CNN_NT, fwd_lds(6), num_samples)), dim3(CNN_NT),
                                        fwd_lds(6), s, in, wscratch, a2, p1, amax, relu_mask);
-    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, fwd_lds(4), num_samples)), dim3(CNN_NT),
+    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, CNN_NT, fwd_lds(4), num_samples)), dim3(CNN_NT),
                             fwd_lds(4), s, in, wscratch, a2, p1, amax, relu_mask);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
@@ -502,9 +511,9 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
     const int cin = agent >= 0 ? 6 : 4;
     hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, (const float*)nullptr, (const float*)nullptr, w2,
                        (const float*)nullptr, wscratch);
-    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(cnn_grid(rs_cnn_bwd_kernel<6>, bwd_lds(6), num_samples)), dim3(CNN_NT),
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_bwd_kernel<6>, dim3(cnn_grid(rs_cnn_bwd_kernel<6>, CNN_NT_BWD, bwd_lds(6), num_samples)), dim3(CNN_NT_BWD),
                                        bwd_lds(6), s, in, wscratch, da2, relu_mask, p1, amax, slab);
-    else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(cnn_grid(rs_cnn_bwd_kernel<4>, bwd_lds(4), num_samples)), dim3(CNN_NT),
+    else hipLaunchKernelGGL(rs_cnn_bwd_kernel<4>, dim3(cnn_grid(rs_cnn_bwd_kernel<4>, CNN_NT_BWD, bwd_lds(4), num_samples)), dim3(CNN_NT_BWD),
                             bwd_lds(4), s, in, wscratch, da2, relu_mask, p1, amax, slab);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
