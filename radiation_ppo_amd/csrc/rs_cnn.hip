@@ -33,6 +33,9 @@ namespace {
 #define CNN_BWD_PREFETCH 1
 #endif
 constexpr int CNN_NT = 192;                 // forward: 3 waves per workgroup; 169 threads own a pooled cell / pixel
+#ifndef CNN_FWD_WAVES
+#define CNN_FWD_WAVES 3
+#endif
 #ifndef CNN_NTB
 #define CNN_NTB 256
 #endif
@@ -154,7 +157,7 @@ __device__ __forceinline__ void cnn_clear_onehots(float* xp, int loc, int pc) {
 // training p1 [S][8][169] (pooled activations) + amax [S][8][169] (which pixel of the 2x2 window won, 0..3 in
 // row-major order; first maximum wins like torch's CPU max_pool2d).
 template <int CIN>
-__global__ void __launch_bounds__(CNN_NT, 3) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
+__global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
                                                             float* __restrict__ p1g, uint8_t* __restrict__ amax,
                                                             uint16_t* __restrict__ relu_mask) {
     extern __shared__ __align__(16) float smem[];
