@@ -12,7 +12,7 @@ Saved sets use the reference's layout `env_dict["env_<i>"] = (src_coords, det_co
 environment's own spawn rules (the reference's pickled sets are not read: they are untrusted binary files).
 """
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List
 
 import numpy as np
 import torch
@@ -20,12 +20,6 @@ import torch
 from . import _lib
 from .envs import RadSearchVec
 from .ppo import DeviceWelford, VecAgentPPO
-
-
-@dataclass
-class Distribution:                      # evaluate.py:51-57
-    unique: Dict = field(default_factory=dict)
-    counts: Dict = field(default_factory=dict)
 
 
 @dataclass
@@ -48,10 +42,6 @@ class MonteCarloResults:                 # evaluate.py:60-68
 
 def median(data) -> np.float32:          # evaluate.py:78-80
     return np.median(data) if len(data) > 0 else np.nan
-
-
-def variance(data) -> np.float32:        # evaluate.py:82-84
-    return np.var(np.array(data) / len(data)) if len(data) > 0 else np.nan
 
 
 def sample_test_environments(count: int, obstruction_count: int = 0, enforce_grid_boundaries: bool = True, seed: int = 0,

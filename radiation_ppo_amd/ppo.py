@@ -11,8 +11,8 @@ Mirrors (paths relative to the reference root):
                          StepLR(100, 0.99)); N envs play the role of the reference's N MPI ranks
                          (gradient = mean over ranks of each rank's mean over its episodes).
 """
-from dataclasses import dataclass, field
-from typing import Any, Dict, List, Optional
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
 
 import torch
 import torch.distributed as dist
