@@ -251,3 +251,24 @@ def test_cnn_update_losses_and_gradients_match_reference(golden_dir):
         assert np.allclose(p.grad.cpu().numpy(), g["ga_" + k], rtol=2e-4, atol=1e-6), k
     for k, p in ag.critic.named_parameters():
         assert np.allclose(p.grad.cpu().numpy(), g["gc_" + k], rtol=2e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("A", [1, 3])
+def test_cnn_train_entry_point_individual_critics(A):
+    """global_critic_flag=False: every agent owns and updates its own critic (train.py:234-246); A = 1 is the
+    single-agent harness of algos/test_cnn."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.train import train_PPO
+    env = RadSearchVec(16, number_agents=A, obstruction_count=-1, enforce_grid_boundaries=True, seed=6)
+    sim = train_PPO(env=env, logger_kwargs={}, ppo_kwargs=dict(steps_per_epoch=24, steps_per_episode=8, number_of_agents=A,
+                                                               train_pi_iters=2, train_v_iters=2),
+                    seed=6, number_of_agents=A, actor_critic_architecture="cnn", global_critic_flag=False,
+                    steps_per_epoch=24, steps_per_episode=8, total_epochs=2)
+    critics = [sim.agents[i].critic for i in range(A)]
+    assert len({id(c) for c in critics}) == A
+    before = [[p.detach().clone() for p in c.parameters()] for c in critics]
+    sim.train()
+    for i in range(A):
+        rows = sim.loggers[i].rows
+        assert len(rows) == 2 and np.isfinite(rows[1]["loss_policy"]) and np.isfinite(rows[1]["loss_critic"])
+        assert any(not torch.equal(a, b) for a, b in zip(before[i], critics[i].parameters()))     # each critic was trained
