@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(256, 1) rs_ppo_grad_kernel(RsMlpParams prm, rs
 }
 
 #include "rs_ppo_grad2.hpp"
+#include "rs_ppo_grad3.hpp"
 
 // deterministic reduction of the per-wave slabs: a workgroup owns 64 consecutive parameters; 16 thread
 // groups each sum a fixed 1/16 of the slabs in order (coalesced 256-byte rows), then the 16 partial sums are
@@ -704,7 +705,7 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
 
 static int rs_grad_version() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("RS_GRAD_V"); v = (e && e[0] == '1') ? 1 : 2; }
+    if (v < 0) { const char* e = getenv("RS_GRAD_V"); v = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : 2); }
     return v;
 }
 
@@ -734,7 +735,8 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     if (!actor || !critic || !batch || !grads || !stats || !workspace || batch->M < 1) return RS_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool v2 = rs_grad_version() == 2;
+    const int ver = rs_grad_version();
+    const bool v2 = ver >= 2;                                        // v3 = v2 with split-bf16 matrix instructions (opt-in)
     const int waves = v2 ? RS_GRAD_BLOCKS : RS_GRAD_BLOCKS * 4;      // v2 reduces its 8 waves in LDS: one slab per workgroup
     float* pa = static_cast<float*>(workspace);
     float* pc = pa + (size_t)waves * rs_net_params(8);
@@ -744,14 +746,19 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     const size_t lds_a = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(8) : rs_grad_lds_floats(8));
     const size_t lds_c = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(1) : rs_grad_lds_floats(1));
     if (!attr_set) {
-        const void* ka = v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<8>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>);
-        const void* kc = v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<1>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>);
+        const void* ka = ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<8>)
+                       : (v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<8>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>));
+        const void* kc = ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<1>)
+                       : (v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<1>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>));
         if (hipFuncSetAttribute(ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
             hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
             return RS_ERR_HIP;
         attr_set = true;
     }
-    if (v2) {
+    if (ver == 3) {
+        hipLaunchKernelGGL(rs_ppo_grad3_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
+        hipLaunchKernelGGL(rs_ppo_grad3_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    } else if (v2) {
         hipLaunchKernelGGL(rs_ppo_grad2_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
         hipLaunchKernelGGL(rs_ppo_grad2_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
     } else {
