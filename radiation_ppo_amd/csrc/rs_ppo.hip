@@ -705,13 +705,14 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
 
 static int rs_grad_version() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("RS_GRAD_V"); v = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : 2); }
+    if (v < 0) { const char* e = getenv("RS_GRAD_V"); v = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : ((e && e[0] == '4') ? 4 : 2)); }
     return v;
 }
 
 size_t rs_ppo_grad_workspace_bytes(void) {
     const size_t waves = RS_GRAD_BLOCKS * 8;
-    return waves * (size_t)(rs_net_params(8) + rs_net_params(1)) * sizeof(float) + 2 * waves * 5 * sizeof(double) + 512;
+    return waves * (size_t)(rs_net_params(8) + rs_net_params(1)) * sizeof(float) + 2 * waves * 5 * sizeof(double) + 512
+           + 2 * (2 * 2 * 4 * 64 * 8 * sizeof(uint16_t)) + 256;          // v4: third bf16 pieces of the layer-2 weights, both nets
 }
 
 int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
@@ -736,28 +737,37 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return RS_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ver = rs_grad_version();
-    const bool v2 = ver >= 2;                                        // v3 = v2 with split-bf16 matrix instructions (opt-in)
+    const bool v2 = ver >= 2;                                        // v3 / v4 = v2 with split-bf16 matrix instructions (opt-in)
     const int waves = v2 ? RS_GRAD_BLOCKS : RS_GRAD_BLOCKS * 4;      // v2 reduces its 8 waves in LDS: one slab per workgroup
     float* pa = static_cast<float*>(workspace);
     float* pc = pa + (size_t)waves * rs_net_params(8);
     double* sa = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pc + (size_t)waves * rs_net_params(1)) + 255) & ~uintptr_t(255));
     double* sc = sa + (size_t)waves * 5;
+    __bf16* xa = reinterpret_cast<__bf16*>((reinterpret_cast<uintptr_t>(sc + (size_t)waves * 5) + 255) & ~uintptr_t(255));
+    __bf16* xc = xa + 2 * 2 * 4 * 64 * 8;
     static bool attr_set = false;
     const size_t lds_a = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(8) : rs_grad_lds_floats(8));
     const size_t lds_c = sizeof(float) * (size_t)(v2 ? rs_grad2_lds_floats(1) : rs_grad_lds_floats(1));
     if (!attr_set) {
-        const void* ka = ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<8>)
+        const void* ka = ver == 4 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<8, 6>)
+                       : ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<8, 3>)
                        : (v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<8>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<8>));
-        const void* kc = ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<1>)
+        const void* kc = ver == 4 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<1, 6>)
+                       : ver == 3 ? reinterpret_cast<const void*>(rs_ppo_grad3_kernel<1, 3>)
                        : (v2 ? reinterpret_cast<const void*>(rs_ppo_grad2_kernel<1>) : reinterpret_cast<const void*>(rs_ppo_grad_kernel<1>));
         if (hipFuncSetAttribute(ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
             hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
             return RS_ERR_HIP;
         attr_set = true;
     }
-    if (ver == 3) {
-        hipLaunchKernelGGL(rs_ppo_grad3_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
-        hipLaunchKernelGGL(rs_ppo_grad3_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    if (ver == 4) {
+        hipLaunchKernelGGL(rs_ppo_prep_kernel, dim3(8), dim3(512), 0, s, to_dev(actor), xa);
+        hipLaunchKernelGGL(rs_ppo_prep_kernel, dim3(8), dim3(512), 0, s, to_dev(critic), xc);
+        hipLaunchKernelGGL((rs_ppo_grad3_kernel<8, 6>), dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag, xa);
+        hipLaunchKernelGGL((rs_ppo_grad3_kernel<1, 6>), dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag, xc);
+    } else if (ver == 3) {
+        hipLaunchKernelGGL((rs_ppo_grad3_kernel<8, 3>), dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag, xa);
+        hipLaunchKernelGGL((rs_ppo_grad3_kernel<1, 3>), dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag, xc);
     } else if (v2) {
         hipLaunchKernelGGL(rs_ppo_grad2_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
         hipLaunchKernelGGL(rs_ppo_grad2_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);

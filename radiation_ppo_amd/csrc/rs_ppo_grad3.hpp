@@ -1,9 +1,12 @@
-// rs_ppo_grad3.hpp -- K7 v3 (opt-in, RS_GRAD_V=3): v2 with its three 64x64 GEMMs per sample group -- forward layer 2,
-// dh1 = W2^T dpre2, dW2 = dpre2 . h1^T -- moved from v_mfma_f32_32x32x2_f32 to split-bf16 matrix instructions:
-// every f32 operand x is written x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and a product is accumulated in
-// float32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (3 instructions of 32 cycles per 16-deep k-step
-// instead of 8 of 64 cycles).  The dropped lo*lo term and the 16-bit operand mantissas cost ~4e-6 relative error
-// against 2.7e-7 for the f32 path (scripts/bf16_split_study.py); the default stays v2 (exact f32).
+// rs_ppo_grad3.hpp -- K7 v3 / v4 (opt-in, RS_GRAD_V=3 / 4): v2 with its three 64x64 GEMMs per sample group -- forward
+// layer 2, dh1 = W2^T dpre2, dW2 = dpre2 . h1^T -- moved from v_mfma_f32_32x32x2_f32 to split-bf16 matrix
+// instructions (v_mfma_f32_32x32x16_bf16: 32 cycles per 16-deep k-step against 8 x 64 cycles).  Every f32 operand is
+// written as a sum of bf16 pieces, x = hi + lo (+ lo2), each the bf16 rounding of what is left, and a product is
+// accumulated in float32 from the significant cross terms:
+//   TERMS = 3 (v3): hi*hi + hi*lo + lo*hi                      16-bit operands, ~4e-6 relative error
+//   TERMS = 6 (v4): + hi*lo2 + lo2*hi + lo*lo                  24-bit operands, as accurate as the f32 instruction
+// (scripts/bf16_split_study.py).  The third weight pieces do not fit the 160 KB of LDS next to the sample tiles: they
+// are produced once per pass by rs_ppo_prep_kernel into 16 KB of the workspace and read through L1.
 // Everything else (layer 1, output layer, dh2, dW3, dW1, LDS tiles, reduction, results layout) is v2 unchanged.
 #pragma once
 #include "rs_mlp.hpp"
@@ -11,29 +14,56 @@
 
 typedef __bf16 rs_bf16x8 __attribute__((ext_vector_type(8)));
 
-// 8 floats -> bf16 hi / lo fragments (round to nearest even twice)
-__device__ __forceinline__ void rs_split8(const float (&x)[8], rs_bf16x8& hi, rs_bf16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 hh = (__bf16)x[i];
-        hi[i] = hh;
-        lo[i] = (__bf16)(x[i] - (float)hh);
-    }
-}
 // hidden unit supplied as k-element i of lane half kg in 16-deep step s (4 steps cover the 64 units):
 // the 8 accumulator registers 8*(s&1) .. +7 of tile s>>1
 __device__ __forceinline__ int rs_unit16(int s, int kg, int i) { return 32 * (s >> 1) + rs_kappa(8 * (s & 1) + i, kg); }
-#define RS_MFMA_BF16X3(ACC, AH, AL, BH, BL)                                   \
-    do {                                                                       \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, ACC, 0, 0, 0);   \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, ACC, 0, 0, 0);   \
-    } while (0)
+struct RsPieces { rs_bf16x8 p0, p1, p2; };       // hi, lo, lo2 (p2 unused when TERMS == 3)
+template <int TERMS>
+__device__ __forceinline__ RsPieces rs_split(const float (&x)[8]) {
+    RsPieces r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 a = (__bf16)x[i];
+        const float r1 = x[i] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        r.p0[i] = a; r.p1[i] = b;
+        r.p2[i] = (TERMS == 6) ? (__bf16)(r1 - (float)b) : (__bf16)0.0f;
+    }
+    return r;
+}
+// smallest terms first into the accumulator would be marginally better; the order is fixed (reproducible)
+template <int TERMS>
+__device__ __forceinline__ void rs_mfma_split(f32x16& acc, const RsPieces& a, const RsPieces& b) {
+    if (TERMS == 6) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, acc, 0, 0, 0);
+}
+
+// third bf16 piece of the layer-2 weight fragments, [fwd 2x4x64x8 | bwd 2x4x64x8] (same order as the LDS fragments)
+__global__ void rs_ppo_prep_kernel(RsMlpParams prm, __bf16* __restrict__ w2x) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * 4 * 64 * 8; e += gridDim.x * blockDim.x) {
+        const int i = e & 7, l = (e >> 3) & 63, sx = (e >> 9) & 3, tile = e >> 11;
+        const int u = rs_unit16(sx, l >> 5, i);
+        const float vf = RS_TANH_PRESCALE * prm.w2[(32 * tile + (l & 31)) * RS_HID + u];
+        const float vb = prm.w2[u * RS_HID + 32 * tile + (l & 31)];
+        const __bf16 f0 = (__bf16)vf, b0 = (__bf16)vb;
+        const float fr = vf - (float)f0, br = vb - (float)b0;
+        const __bf16 f1 = (__bf16)fr, b1 = (__bf16)br;
+        w2x[e] = (__bf16)(fr - (float)f1);
+        w2x[2 * 4 * 64 * 8 + e] = (__bf16)(br - (float)b1);
+    }
+}
 
 
-template <int NOUT>
+template <int NOUT, int TERMS>
 __global__ void __launch_bounds__(512, 2) rs_ppo_grad3_kernel(RsMlpParams prm, rs_ppo_batch B, float* __restrict__ partial,
-                                                              double* __restrict__ stat_partial, const int* __restrict__ stop) {
+                                                              double* __restrict__ stat_partial, const int* __restrict__ stop,
+                                                              const __bf16* __restrict__ w2x) {
     extern __shared__ __align__(16) float smem_f[];
     if (stop && *stop) return;
     RsMlpLds<NOUT> W;
@@ -146,13 +176,14 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad3_kernel(RsMlpParams prm, r
                 float v8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v8[i] = H1[sx >> 1][8 * (sx & 1) + i];
-                rs_bf16x8 bh, bl;
-                rs_split8(v8, bh, bl);
+                const RsPieces bp = rs_split<TERMS>(v8);
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    const rs_bf16x8 ah = *reinterpret_cast<const rs_bf16x8*>(w2h + ((ot * 4 + sx) * 64 + lane) * 8);
-                    const rs_bf16x8 al = *reinterpret_cast<const rs_bf16x8*>(w2l + ((ot * 4 + sx) * 64 + lane) * 8);
-                    RS_MFMA_BF16X3(H2[ot], ah, al, bh, bl);
+                    RsPieces ap;
+                    ap.p0 = *reinterpret_cast<const rs_bf16x8*>(w2h + ((ot * 4 + sx) * 64 + lane) * 8);
+                    ap.p1 = *reinterpret_cast<const rs_bf16x8*>(w2l + ((ot * 4 + sx) * 64 + lane) * 8);
+                    if (TERMS == 6) ap.p2 = *reinterpret_cast<const rs_bf16x8*>(w2x + ((ot * 4 + sx) * 64 + lane) * 8);
+                    rs_mfma_split<TERMS>(H2[ot], ap, bp);
                 }
             }
         }
@@ -295,13 +326,14 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad3_kernel(RsMlpParams prm, r
                 float v8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v8[i] = H2[sx >> 1][8 * (sx & 1) + i];
-                rs_bf16x8 bh, bl;
-                rs_split8(v8, bh, bl);
+                const RsPieces bp = rs_split<TERMS>(v8);
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const rs_bf16x8 ah = *reinterpret_cast<const rs_bf16x8*>(w2th + ((it * 4 + sx) * 64 + lane) * 8);
-                    const rs_bf16x8 al = *reinterpret_cast<const rs_bf16x8*>(w2tl + ((it * 4 + sx) * 64 + lane) * 8);
-                    RS_MFMA_BF16X3(D1[it], ah, al, bh, bl);
+                    RsPieces ap;
+                    ap.p0 = *reinterpret_cast<const rs_bf16x8*>(w2th + ((it * 4 + sx) * 64 + lane) * 8);
+                    ap.p1 = *reinterpret_cast<const rs_bf16x8*>(w2tl + ((it * 4 + sx) * 64 + lane) * 8);
+                    if (TERMS == 6) ap.p2 = *reinterpret_cast<const rs_bf16x8*>(w2x + 2 * 4 * 64 * 8 + ((it * 4 + sx) * 64 + lane) * 8);
+                    rs_mfma_split<TERMS>(D1[it], ap, bp);
                 }
             }
         }
@@ -328,15 +360,13 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad3_kernel(RsMlpParams prm, r
                 float v8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v8[i] = Pt[c * RS_T2 + 16 * s2 + 8 * h + i];
-                rs_bf16x8 ah, al;
-                rs_split8(v8, ah, al);
+                const RsPieces ap = rs_split<TERMS>(v8);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v8[i] = Qt[(32 * kt + c) * RS_T2 + 16 * s2 + 8 * h + i];
-                    rs_bf16x8 bh, bl;
-                    rs_split8(v8, bh, bl);
-                    RS_MFMA_BF16X3(acc2[it][kt], ah, al, bh, bl);
+                    const RsPieces bp = rs_split<TERMS>(v8);
+                    rs_mfma_split<TERMS>(acc2[it][kt], ap, bp);
                 }
             }
             // db2[32it + c] += sum over the 32 samples of dpre2: lane (c, h) sums samples 16h .. 16h+15 of row c
