@@ -1,44 +1,66 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the radiation-search PPO hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--configs 3,4|none]
 
-Workload (BASELINE.json configs[1]): single-agent RadSearch, 1 source, no obstructions, 4096 envs per
+Headline workload (BASELINE.json configs[1]): single-agent RadSearch, 1 source, no obstructions, 4096 envs per
 GPU, 2x64 MLP actor-critic, walls enforced, 480 steps/epoch, 120 steps/episode, synthetic spawns from
 the Philox streams (seed 289714752 = the reference's robust_seed(2)).
 
 One bench "step" = one full PPO iteration: a rollout of 480 lock-steps of all envs with the policy in
 the loop (forward, sampling, env step, buffer write, resets), the GAE pass, and the complete PPO update
 (<= 40 Adam steps with KL early stop).  Nothing is skipped inside the timed region.
-    value        = env steps/s over the whole job  = K * 480 * (4096 * N) / wall
+    value        = env steps/s over the whole job  = K * 480 * (envs per GPU * N) / wall
     ms_per_step  = wall per PPO iteration (PPO iters/s = 1000 / ms_per_step)
-Rank 0 prints ONE JSON line; it also carries `roofline` (the dominant kernel of the iteration: the fused PPO
-loss+gradient pass, MFMA bound), `roofline_env_step` / `roofline_env_step_large_n` (the env-step kernel, HBM
-class, at 4096 and 2^20 envs) -- all timed with HIP events in this run -- and `cpu_baseline` (the oracle, a
-port of the reference's Python env, on the host cores).
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+    roofline                  the dominant kernel of the iteration (fused PPO loss+gradient pass, MFMA bound)
+    roofline_env_step[_large_n], roofline_gae   the HBM-class kernels (K1 at 4096 and 2^20 envs, K4)
+    cpu_baseline              the oracle (a port of the reference's env) on the host cores
+    configs                   BASELINE configs 3 and 4 at their stated sizes: one or two PPO iterations each with
+                              ms_per_step, phase split and their own roofline figures (N = 1 only)
+all timed in this run with HIP events on the launch stream.
+
+Multi-GPU: `--gpus N` with no launcher in the environment starts its own N ranks (torch.distributed.run,
+one process per GPU, RCCL) BEFORE touching the GPU and relays rank 0's line; under the driver's own
+`python -m torch.distributed.run ... bench.py --gpus N` it reads RANK/LOCAL_RANK/WORLD_SIZE as usual.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 SEED = 289714752
 ENVS_PER_GPU = 4096
 T_EPOCH, L_EPISODE = 480, 120
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak = f32 vector peak (MI355X_MICROARCH.md, Matrix cores table)
 # algorithmic bytes per agent-step of K1 at A=1, no obstacles (DESIGN.md "K1 bytes"):
 #   read : x,y 8 + sp,prev 16 + oob_count 4 + aflags 1 + src 8 + intensity,bkg 8 + iter,tstep,episode 12 + done 1 + action 1 = 59
 #   write: obs 44 + reward 4 + team 4 + done 1 + info 7 + x,y 8 + sp,prev 16 + oob_count 4 + aflags 1 + done,iter,tstep 9 = 98
 K1_BYTES_PER_AGENT_STEP = 157
+# K4 (rs_gae): read rew 4, val 4, cut 1, last_val 4; write adv 4, ret 4
+GAE_BYTES_PER_SAMPLE = 21
+# K6 (rs_rollout): buffer row written per env-step: obs 44 + act 8 + logp 4 + val 4 + rew 4 + last_val 4 + cut 1 + source_tar 8
+ROLLOUT_BYTES_PER_ENV_STEP = 77
+# algorithmic FLOPs per sample of one PPO loss+gradient pass over the FF_core actor+critic (DESIGN.md section 3):
+#   forward  2*(11*64 + 64*64 + 64*8) + 2*(11*64 + 64*64 + 64*1)                     = 20 352  (SURVEY 8d: 20.4 kFLOP)
+#   backward 2*(512+512+4096+4096+704) [actor dW3,dh2,dW2,dh1,dW1] + 2*(64+64+4096+4096+704) = 37 888
+PPO_GRAD_FLOPS_PER_SAMPLE = 58240
+# CNN trunk (conv3x3(Cin->8)-ReLU-pool-conv3x3(8->16)-ReLU) multiply-adds per 27x27 image, zero-padded borders counted:
+#   forward: conv1 729*9*Cin*8 + conv2 169*9*8*16;  backward (weight gradients + dP1): dW2 + dP1 = 2 * conv2, dW1 = conv1 / 4
+#   (only the arg-max pixel of each pool window carries gradient)
+def cnn_trunk_flops(cin: int, backward: bool) -> float:
+    c1, c2 = 729 * 9 * cin * 8, 169 * 9 * 8 * 16
+    return 2.0 * ((2 * c2 + c1 / 4) if backward else (c1 + c2))
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _py_worker(args):
     wid, n_envs, seconds = args
     import random
@@ -62,7 +84,6 @@ def _py_worker(args):
 
 def _c_lib():
     import ctypes as C
-    import subprocess
     so = os.path.join(ROOT, "oracle", "_build", "librs_oracle.so")
     if not os.path.exists(so):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
@@ -80,11 +101,11 @@ def _c_worker(args):
     return abs(n), time.perf_counter() - t0
 
 
-def cpu_baseline(seconds: float = 10.0):
+def cpu_baseline(seconds: float = 8.0):
     """The oracle on the host cores (kind "port"): the C restatement of the reference's RadSearch.step/reset
     (oracle/radsearch_oracle.c, pinned to the Python oracle and through it to the reference's golden vectors), one
     process per core, 16 obstacle-free single-agent envs each, uniform random actions, ~`seconds` of work per core.
-    The pure-Python oracle (closest to the reference's own Python env.step) is timed on one core beside it."""
+    The pure-Python oracle (closest to the reference's own Python env.step) is timed on one core and on all cores."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
     probe = _c_worker((0, 16, 2_000_000))
@@ -92,24 +113,57 @@ def cpu_baseline(seconds: float = 10.0):
     target = int(rate * seconds)
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.map(_c_worker, [(w, 16, target) for w in range(cores)])
+        py_all = pool.map(_py_worker, [(w, 16, min(seconds, 4.0)) for w in range(cores)])
     total = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
-    py = _py_worker((0, 16, min(seconds, 4.0)))
+    py = _py_worker((0, 16, min(seconds, 3.0)))
     return {"value": total / wall, "unit": "env steps/s", "cores": cores, "kind": "port",
             "single_core_value": rate, "python_port_single_core_value": py[0] / py[1],
+            "python_port_all_cores_value": sum(r[0] for r in py_all) / max(r[1] for r in py_all),
             "sample": f"{cores} procs x 16 obstacle-free single-agent envs, uniform random actions, {target} env steps "
-                      f"(~{seconds:.0f} s) each, oracle/radsearch_oracle.c (-O2, scalar); env step + reset only, no policy"}
+                      f"(~{seconds:.0f} s) each, oracle/radsearch_oracle.c (-O2, scalar); env step + reset only, no policy; "
+                      f"python port: oracle/radsearch_oracle.py, same envs, ~{min(seconds, 4.0):.0f} s per process"}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) as a CHILD job and
+    relay rank 0's JSON line.  Nothing in this parent process has touched the GPU (no HIP call, no torch.cuda init)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank job failed (exit code {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ kernel timing helpers
+def _ms(pairs):
+    return [a.elapsed_time(b) for a, b in pairs]
 
 
 def time_step_kernel(env, reps: int = 400):
     """Average duration of the env-step kernel (rs_step_kernel) at this N, HIP events on the launch stream."""
+    import torch
     N, A = env.num_envs, env.number_agents
     acts = torch.randint(0, 9, (N, A), device=env.device).to(torch.int8)
     env.reset()
     for _ in range(20):
         env.step(acts)
     torch.cuda.synchronize()
-    # per-launch brackets: event, launch, event -- each kernel is timed alone
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for i in range(reps):
         ev[i][0].record()
@@ -118,8 +172,7 @@ def time_step_kernel(env, reps: int = 400):
         if i % 97 == 96:
             env.reset()
     torch.cuda.synchronize()
-    ds = sorted(a.elapsed_time(b) for a, b in ev)
-    # back-to-back train (kernel + launch gap), for reference
+    ds = sorted(_ms(ev))
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
     for _ in range(reps):
@@ -129,16 +182,10 @@ def time_step_kernel(env, reps: int = 400):
     return {"avg_ms": sum(ds) / len(ds), "median_ms": ds[len(ds) // 2], "train_ms": t0.elapsed_time(t1) / reps}
 
 
-MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (MI355X_MICROARCH.md, Matrix cores table)
-# algorithmic FLOPs per sample of one PPO loss+gradient pass over the FF_core actor+critic (DESIGN.md section 3):
-#   forward  2*(11*64 + 64*64 + 64*8) + 2*(11*64 + 64*64 + 64*1)                     = 20 352  (SURVEY 8d: 20.4 kFLOP)
-#   backward 2*(512+512+4096+4096+704) [actor dW3,dh2,dW2,dh1,dW1] + 2*(64+64+4096+4096+704) = 37 888
-PPO_GRAD_FLOPS_PER_SAMPLE = 58240
-
-
 def time_grad_pass(col, reps: int = 20):
     """Average duration of one fused PPO loss+gradient pass (rs_ppo_grad: actor kernel + critic kernel + slab
-    reduce) over the epoch's batch, HIP events on the launch stream."""
+    reduce) over the epoch's batch, back to back, HIP events on the launch stream."""
+    import torch
     from radiation_ppo_amd.ppo import FusedPPOGrad
     buf = col.buf
     ag = col.agents[0]
@@ -157,48 +204,209 @@ def time_grad_pass(col, reps: int = 20):
     return e0.elapsed_time(e1) / reps, X.shape[0]
 
 
+def grad_roofline(events, stop_iters, iters_per_update: int, samples: int, iso_ms=None, traffic=None):
+    """roofline object of K7 from the HIP-event brackets of the timed region.  Launches after a KL early stop are
+    microsecond no-ops: only the first `stop_iteration` brackets of each update enter the mean."""
+    ds = _ms(events)
+    kept = []
+    for i, k in enumerate(stop_iters):
+        kept += ds[i * iters_per_update: i * iters_per_update + k]
+    if not kept:
+        kept = [iso_ms] if iso_ms else []
+    g_ms = sum(kept) / max(len(kept), 1)
+    tfl = PPO_GRAD_FLOPS_PER_SAMPLE * samples / (g_ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": "rs_ppo_grad2_kernel<8> + rs_ppo_grad2_kernel<1> (+ rs_ppo_reduce_kernel)",
+           "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
+           "traffic": traffic["grad_pass_bytes_per_launch"] if traffic else None,
+           "traffic_source": traffic.get("source") if traffic else None,
+           "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * samples, "samples": samples, "avg_launch_ms": g_ms,
+           "launches_timed": len(kept), "launches_skipped_after_kl_stop": len(ds) - len(kept),
+           "timing": "HIP events on the launch stream around every rs_ppo_grad launch of the timed region",
+           "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
+    if iso_ms is not None:
+        out["avg_launch_ms_isolated"] = iso_ms
+    return out
+
+
 def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json); None if absent."""
+    """HBM bytes per launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json): measured by
+    scripts/pmc_traffic.py on the same command, NOT in this run (counters need their own rocprofv3 passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)
+        with open(files[-1]) as f:
+            d = json.load(f)
+        d["source"] = f"committed profile profiles/{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), not measured in this run"
+        return d
     except Exception:  # noqa: BLE001
         return None
 
 
+# ------------------------------------------------------------------------------------------------ configs 3 and 4
+def run_config3(dev, iters: int = 2, warmup: int = 1):
+    """BASELINE config 3: single agent, 1 source + random obstructions (U{1..5} rectangles per env, resampled every
+    epoch), 8192 envs, 2x64 MLP -- the same PPO iteration as the headline."""
+    import torch
+    from radiation_ppo_amd import _lib
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO
+    N, T, L = 8192, T_EPOCH, L_EPISODE
+    torch.manual_seed(SEED % (2 ** 31))
+    env = RadSearchVec(N, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED, device=dev)
+    ag = {0: VecAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, device=dev)}
+    col = FusedCollector(env, ag, T, L)
+    for _ in range(warmup):
+        col.collect(); col.update()
+    torch.cuda.synchronize()
+    _lib.EVENTS = {}
+    tc = tu = 0.0
+    stops = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        a = time.perf_counter(); col.collect(); torch.cuda.synchronize(); b = time.perf_counter()
+        res = col.update(); torch.cuda.synchronize(); c = time.perf_counter()
+        tc += b - a; tu += c - b
+        stops.append(res[0].stop_iteration)
+    dt = time.perf_counter() - t0
+    ev, _lib.EVENTS = _lib.EVENTS, None
+    roll_ms = sum(_ms(ev["rs_rollout"])) / iters
+    gae_ms = sum(_ms(ev["rs_gae"])) / iters
+    roll_gbs = ROLLOUT_BYTES_PER_ENV_STEP * N * T / (roll_ms * 1e-3) / 1e9
+    # K1<true> on its own at this size (the lane function the rollout runs), HIP events
+    k1 = time_step_kernel(env, reps=200)
+    out = {"workload": "single-agent RadSearch, 1 source + U{1..5} random rectangles per env, 8192 envs, 2x64 MLP, 480 steps/epoch",
+           "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
+           "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
+           "update_adam_steps": stops,
+           "roofline": grad_roofline(ev["rs_ppo_grad"], stops, ag[0].train_pi_iters, N * T),
+           "roofline_rollout": {"bound": "hbm", "kernel": "rs_rollout16_kernel<true>", "achieved": roll_gbs, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": roll_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": roll_ms,
+                                "bytes_per_launch": ROLLOUT_BYTES_PER_ENV_STEP * N * T, "us_per_lock_step": 1e3 * roll_ms / T,
+                                "note": "one launch = 480 lock-steps of 8192 envs with the policy in the loop; latency bound "
+                                        "(f64 env chain + visibility tests per lane), not HBM bound"},
+           "roofline_env_step": {"bound": "hbm", "kernel": "rs_step_kernel<true>", "avg_launch_ms": k1["avg_ms"],
+                                 "achieved": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": None, "bytes_per_launch": K1_BYTES_PER_AGENT_STEP * N,
+                                 "note": "157 B/agent-step counted (obstacle rectangles and cached geodesics not counted)"},
+           "gae_ms": gae_ms}
+    flags = env.error_flags()
+    out["env_error_flags"] = flags
+    del col, env, ag
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_config4(dev, iters: int = 1, warmup: int = 1):
+    """BASELINE config 4: multi-agent RAD-TEAM, 4 agents, CNN actors + global critic on the heat maps, random
+    obstructions, 4096 envs."""
+    import torch
+    from radiation_ppo_amd import _lib
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, T, L, A = 4096, T_EPOCH, L_EPISODE, 4
+    torch.manual_seed(SEED % (2 ** 31))
+    env = RadSearchVec(N, number_agents=A, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED, device=dev)
+    gc = CNNCritic().to(dev)
+    gco = torch.optim.Adam(gc.parameters(), lr=1e-3)
+    ag = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, device=dev) for i in range(A)}
+    col = CNNCollector(env, ag, T, L, True)
+    for _ in range(warmup):
+        col.collect(); col.update()
+    torch.cuda.synchronize()
+    _lib.EVENTS = {}
+    tc = tu = 0.0
+    stops = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        a = time.perf_counter(); col.collect(); torch.cuda.synchronize(); b = time.perf_counter()
+        res = col.update(); torch.cuda.synchronize(); c = time.perf_counter()
+        tc += b - a; tu += c - b
+        stops.append([res[i].stop_iteration for i in range(A)])
+    dt = time.perf_counter() - t0
+    ev, _lib.EVENTS = _lib.EVENTS, None
+    out = {"workload": "multi-agent RAD-TEAM, 4 agents, CNN actors + global critic, U{1..5} random rectangles, 4096 envs, "
+                       "480 steps/epoch; step = 1 PPO iteration (rollout + GAE + 4 x <=40 actor + 40 critic Adam steps)",
+           "envs": N, "agents": A, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
+           "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
+           "update_adam_steps": stops, "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    # K9 / K10: images per launch = the update chunk; FLOP per image from the layer shapes
+    chunk = min(ag[0].chunk, N * T)
+    for name, key, bwd in (("rs_cnn_fwd_kernel (training forward)", "rs_cnn_trunk_forward_train", False),
+                           ("rs_cnn_bwd_kernel", "rs_cnn_trunk_backward", True)):
+        ds = _ms(ev.get(key, []))
+        if ds:
+            ms = sum(ds) / len(ds)
+            # actor launches (6 channels) outnumber critic launches (4 channels) 4:1 with a global critic
+            fl = (4 * cnn_trunk_flops(6, bwd) + cnn_trunk_flops(4, bwd)) / 5.0 * chunk
+            tf = fl / (ms * 1e-3) / 1e12
+            out["roofline_cnn_bwd" if bwd else "roofline_cnn_fwd"] = {
+                "bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms, "launches_timed": len(ds),
+                "images_per_launch": chunk, "flops_per_launch": fl,
+                "note": "f32 vector/matrix peak (157.3 TFLOP/s); average over actor (6-channel) and critic (4-channel) launches"}
+    out["env_error_flags"] = env.error_flags()
+    del col, env, ag, gc, gco
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 4096 envs per GPU (default); strong: 4096 envs in total (SURVEY 8d Metric 2)")
     ap.add_argument("--collector", choices=["fused", "torch"], default="fused")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional tests)")
+    ap.add_argument("--configs", default=None, help="comma list of extra BASELINE configs to run at N=1 (default '3,4'; 'none')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)      # functional multi-rank tests on a 1-GPU box share device 0
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+            one = torch.ones(1, device=f"cuda:{local}")
+            dist.all_reduce(one)                               # an RCCL all-reduce over xGMI: counts the ranks that took part
+            rccl_ranks = int(one.item())
         else:
             dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(local)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device(f"cuda:{local}")
 
+    from radiation_ppo_amd import _lib
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.ppo import Collector, FusedCollector, VecAgentPPO
 
-    N = args.envs_per_gpu
+    if args.envs_per_gpu is not None:
+        N = args.envs_per_gpu
+    else:
+        N = ENVS_PER_GPU if args.scaling == "weak" else ENVS_PER_GPU // world
     torch.manual_seed(SEED % (2 ** 31))
     env = RadSearchVec(N, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED,
                        env_id_base=rank * N, device=dev)
@@ -229,15 +437,15 @@ def main():
 
     for _ in range(args.warmup):
         one_iter(False)
-    fused = getattr(agents[0], "_fused", None)
-    if fused is not None:
-        fused.launch_events = []          # HIP events around every rs_ppo_grad launch of the timed region
+    if rank == 0:
+        _lib.EVENTS = {}                    # HIP events around the library launches of the timed region
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_iter(True)
     barrier()
     dt = time.perf_counter() - t0
+    events, _lib.EVENTS = (_lib.EVENTS or {}), None
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
@@ -247,63 +455,81 @@ def main():
     result = {
         "metric": "env steps/sec (whole node) at 4096 envs; PPO iters/sec at 1/2/4/8 GPUs",
         "value": env_steps / dt, "unit": "env steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32 policy / f64+int32 env", "data": "synthetic",
-        "config": {"workload": "single-agent RadSearch, 1 source, no obstructions, 4096 envs/GPU, 2x64 MLP, "
+        "config": {"workload": f"single-agent RadSearch, 1 source, no obstructions, {N} envs/GPU, 2x64 MLP, "
                                "480 steps/epoch, 120 steps/episode, walls enforced; step = 1 PPO iteration "
                                "(rollout + GAE + full update)",
-                   "envs_per_gpu": N, "steps_per_epoch": T_EPOCH, "steps_per_episode": L_EPISODE,
+                   "envs_per_gpu": N, "envs_total": N * world, "steps_per_epoch": T_EPOCH, "steps_per_episode": L_EPISODE,
                    "collector": args.collector,
-                   "parallelism": f"dp{world} (envs sharded, RCCL grad all-reduce)"},
+                   "parallelism": f"dp{world} (envs sharded by env_id_base, RCCL grad all-reduce per Adam step)"},
         "ppo_iters_per_s": args.steps / dt,
         "collector_env_steps_per_s": args.steps * T_EPOCH * N / max(phases["collect"], 1e-9) * world,
         "phase_ms": {k: 1000.0 * v / args.steps for k, v in phases.items()},
         "update_adam_steps": stop_iters,
+        "backend": args.backend if world > 1 else None, "rccl_ranks": rccl_ranks,
     }
 
     if rank == 0:
         pmc = pmc_traffic() if N == ENVS_PER_GPU else None
-        # dominant kernel of the PPO iteration: the fused loss+gradient pass (<= 40 launches per iteration), MFMA bound
         if args.collector == "fused":
-            evs = (fused.launch_events or []) if fused is not None else []
-            if fused is not None:
-                fused.launch_events = None
             g_iso_ms, g_m = time_grad_pass(col)
-            g_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1) if evs else g_iso_ms
-            tfl = PPO_GRAD_FLOPS_PER_SAMPLE * g_m / (g_ms * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "rs_ppo_grad2_kernel<8> + rs_ppo_grad2_kernel<1> (+ rs_ppo_reduce_kernel)",
-                                  "achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F32_PEAK_TFLOPS,
-                                  "traffic": pmc["grad_pass_bytes_per_launch"] if pmc else None,
-                                  "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if pmc else None,
-                                  "flops_per_launch": PPO_GRAD_FLOPS_PER_SAMPLE * g_m, "samples": g_m,
-                                  "avg_launch_ms": g_ms, "launches_timed": len(evs), "avg_launch_ms_isolated": g_iso_ms,
-                                  "timing": "HIP events on the launch stream around every rs_ppo_grad launch of the timed region",
-                                  "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)"}
+            result["roofline"] = grad_roofline(events.get("rs_ppo_grad", []), stop_iters, agents[0].train_pi_iters, g_m,
+                                               iso_ms=g_iso_ms, traffic=pmc)
+            if events.get("rs_rollout"):
+                r_ms = sum(_ms(events["rs_rollout"])) / len(events["rs_rollout"])
+                r_gbs = ROLLOUT_BYTES_PER_ENV_STEP * N * T_EPOCH / (r_ms * 1e-3) / 1e9
+                result["roofline_rollout"] = {"bound": "hbm", "kernel": "rs_rollout16_kernel<false>", "achieved": r_gbs,
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_gbs / HBM_PEAK_GBS, "traffic": None,
+                                              "avg_launch_ms": r_ms, "bytes_per_launch": ROLLOUT_BYTES_PER_ENV_STEP * N * T_EPOCH,
+                                              "us_per_lock_step": 1e3 * r_ms / T_EPOCH,
+                                              "note": "one launch = 480 lock-steps with the policy in the loop: latency bound"}
+            if events.get("rs_gae"):
+                g_ms = sum(_ms(events["rs_gae"])) / len(events["rs_gae"])
+                g_gbs = GAE_BYTES_PER_SAMPLE * N * T_EPOCH / (g_ms * 1e-3) / 1e9
+                result["roofline_gae"] = {"bound": "hbm", "kernel": "rs_gae_kernel", "achieved": g_gbs, "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": g_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_ms,
+                                          "bytes_per_launch": GAE_BYTES_PER_SAMPLE * N * T_EPOCH}
         k1 = time_step_kernel(env)
         bytes_per_launch = K1_BYTES_PER_AGENT_STEP * N * 1
         achieved = bytes_per_launch / (k1["avg_ms"] * 1e-3) / 1e9
         result["roofline_env_step"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": pmc["env_step_4096_bytes_per_launch"] if pmc else None,
-                              "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1["avg_ms"],
-                              "median_launch_ms": k1["median_ms"], "back_to_back_ms": k1["train_ms"],
-                              "env_only_steps_per_s": N / (k1["train_ms"] * 1e-3),
-                              "note": "4096 envs = 0.64 MB per launch: launch-latency bound, see roofline_env_step_large_n"}
-        # the same kernel where it is bandwidth-sized: 2^20 envs
-        try:
-            big = RadSearchVec(1 << 20, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED, device=dev)
-            kb = time_step_kernel(big, reps=60)
-            bpl = K1_BYTES_PER_AGENT_STEP * (1 << 20)
-            ach = bpl / (kb["avg_ms"] * 1e-3) / 1e9
-            result["roofline_env_step_large_n"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "envs": 1 << 20, "achieved": ach,
-                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                          "traffic": pmc["env_step_1048576_bytes_per_launch"] if pmc else None, "bytes_per_launch": bpl,
-                                          "avg_launch_ms": kb["avg_ms"], "env_only_steps_per_s": (1 << 20) / (kb["train_ms"] * 1e-3)}
-            del big
-        except Exception as e:  # noqa: BLE001
-            result["roofline_env_step_large_n"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+                                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                       "traffic": pmc.get("env_step_4096_bytes_per_launch") if pmc else None,
+                                       "traffic_source": pmc.get("source") if pmc else None,
+                                       "bytes_per_launch": bytes_per_launch, "avg_launch_ms": k1["avg_ms"],
+                                       "median_launch_ms": k1["median_ms"], "back_to_back_ms": k1["train_ms"],
+                                       "env_only_steps_per_s": N / (k1["train_ms"] * 1e-3),
+                                       "note": "4096 envs = 0.64 MB per launch: launch-latency bound, see roofline_env_step_large_n"}
+        if world == 1:
+            # the same kernel where it is bandwidth-sized: 2^20 envs
+            try:
+                big = RadSearchVec(1 << 20, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED, device=dev)
+                kb = time_step_kernel(big, reps=60)
+                bpl = K1_BYTES_PER_AGENT_STEP * (1 << 20)
+                ach = bpl / (kb["avg_ms"] * 1e-3) / 1e9
+                result["roofline_env_step_large_n"] = {"bound": "hbm", "kernel": "rs_step_kernel<false>", "envs": 1 << 20, "achieved": ach,
+                                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                                       "traffic": pmc.get("env_step_1048576_bytes_per_launch") if pmc else None,
+                                                       "traffic_source": pmc.get("source") if pmc else None,
+                                                       "bytes_per_launch": bpl, "avg_launch_ms": kb["avg_ms"],
+                                                       "env_only_steps_per_s": (1 << 20) / (kb["train_ms"] * 1e-3)}
+                del big
+            except Exception as e:  # noqa: BLE001
+                result["roofline_env_step_large_n"] = {"error": repr(e)}
+            which = args.configs if args.configs is not None else ("3,4" if N == ENVS_PER_GPU else "none")
+            extra = {}
+            del col, env
+            torch.cuda.empty_cache()
+            for c in [x.strip() for x in which.split(",") if x.strip() and x.strip() != "none"]:
+                try:
+                    extra[f"config{c}"] = {"3": run_config3, "4": run_config4}[c](dev)
+                except Exception as e:  # noqa: BLE001
+                    extra[f"config{c}"] = {"error": repr(e)}
+            if extra:
+                result["configs"] = extra
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

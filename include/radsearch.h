@@ -117,7 +117,11 @@ int rs_refresh(rs_handle* h, const uint8_t* mask, const int32_t* src_xy, const i
                const int32_t* bkg, const int32_t* num_obs, const int32_t* rects, float* obs, float* reward, float* team,
                uint8_t* done, const rs_info* info, rs_stream_t stream);
 
-/* One lock-step of all N envs.  actions [N,A] int8 in 0..8 (-1 == idle 8).  Outputs as rs_reset.
+/* One lock-step of all N envs.  actions [N,A] int8: 0..8 (-1 == idle 8) = the dict form of RadSearch.step with the
+ * collision rule (rad_search_env.py:645-659); 9 = the reference's step(None) for that agent (no move, stale distances,
+ * :528-567); 16 + a (a in 0..8) = the single-int form `step(a)` (:676-690): action a for the agent, and when ANY agent of
+ * an env carries this form no collision rule is applied in that env (the reference calls agent_step without
+ * proposed_coordinates there).  Outputs as rs_reset.
  * done[n,a] is the env-wide latch as seen when agent a returned (rad_search_env.py:509,613). */
 int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, float* team, uint8_t* done,
             const rs_info* info, rs_stream_t stream);
@@ -185,6 +189,11 @@ typedef struct rs_rollout_args {
     double* ep_ret_sum;
     double* ep_len_sum;
     int32_t* ep_count;
+    /* per-env statistics of the returns of the episodes that ended in this launch (logger columns StdEpRet / MaxEpRet /
+     * MinEpRet, train.py:620): sum of squares, max (-inf when none ended), min (+inf when none ended) */
+    double* ep_ret_sq_sum;
+    float* ep_ret_max;
+    float* ep_ret_min;
 } rs_rollout_args;
 
 int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_rollout_args* args,

@@ -38,7 +38,7 @@ class RsRolloutArgs(C.Structure):
     _fields_ = [("steps_per_epoch", C.c_int32), ("steps_per_episode", C.c_int32)] + [
         (n, C.c_void_p) for n in ("obs", "act", "logp", "val", "rew", "last_val", "cut", "source_tar", "cur_obs", "w_count",
                                   "w_mean", "w_sq", "w_std", "steps_in_ep", "ep_ret", "done_count", "oob_count",
-                                  "ep_ret_sum", "ep_len_sum", "ep_count")]
+                                  "ep_ret_sum", "ep_len_sum", "ep_count", "ep_ret_sq_sum", "ep_ret_max", "ep_ret_min")]
 
 
 class RsPpoBatch(C.Structure):
@@ -98,6 +98,28 @@ SYMBOLS = [
 ]
 
 _lib = None
+
+# Optional kernel timing for bench.py: when EVENTS is a dict, every library call wrapped in `timed(name)` is bracketed by
+# HIP events on the stream it is launched on (torch's current stream) and the pair is appended to EVENTS[name].
+EVENTS = None
+
+
+class timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        self.ev = None
+        if EVENTS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            EVENTS.setdefault(self.name, []).append(self.ev)
+        return False
 
 
 def load():

@@ -468,7 +468,8 @@ struct RsOut {
 // Mirrors step :443-728 / agent_step :460-613; agents are processed in id order because `done`, the
 // team reward and the collision rule are order dependent.
 template <bool HAS_OBS, typename ActFn>
-__device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo& g, int n, ActFn act_of, const RsOut& O) {
+__device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo& g, int n, ActFn act_of, const RsOut& O,
+                                                 bool no_collision_rule = false) {
     const int N = P.N, A = P.A;
     const int sx = P.src_x[n], sy = P.src_y[n];
     const int intensity = P.intensity[n], bkg = P.bkg[n];
@@ -483,7 +484,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
     uint32_t coll_mask = 0;
     bool any_none = false;
     for (int i = 0; i < A; ++i) any_none |= (act_of(i) == RS_ACT_NONE);
-    if (A > 1 && !any_none) {
+    if (A > 1 && !any_none && !no_collision_rule) {
         for (int i = 0; i < A; ++i) {
             int dxi, dyi; rs_action_step(act_of(i), dxi, dyi);
             int tx = P.ax[(size_t)i * N + n] + dxi, ty = P.ay[(size_t)i * N + n] + dyi;

@@ -32,13 +32,16 @@ __global__ void __launch_bounds__(64, (HAS_OBS ? 4 : 1)) rs_step_kernel(RsParams
         o.obs_row = tile + lane * rs_tile_stride(P.A);
         const int8_t* arow = actions + (size_t)n * P.A;
         uint32_t bad = 0;
+        bool single_int = false;                   // 16 + a: RadSearch.step(int) for several agents, no collision rule (:676-690)
+        for (int a = 0; a < P.A; ++a) single_int |= arow[a] >= 16;
         auto act_of = [&](int a) -> int {
             int v = arow[a];
+            if (v >= 16) v -= 16;
             if (v == -1) return RS_IDLE;
-            if (v < 0 || v > 8) { bad = RS_ENVERR_BAD_ACTION; return RS_IDLE; }
-            return v;
+            if (v < 0 || v > RS_ACT_NONE) { bad = RS_ENVERR_BAD_ACTION; return RS_IDLE; }
+            return v;                               // 0..8, or RS_ACT_NONE = step(None) (:528-567)
         };
-        rs_env_step_lane<HAS_OBS>(P, g, n, act_of, o);
+        rs_env_step_lane<HAS_OBS>(P, g, n, act_of, o, single_int);
         if (bad) P.err[n] |= bad;
     }
     __syncthreads();

@@ -1,9 +1,9 @@
-// rs_rollout16.hpp -- K6 v2: the fused collector with 16 envs per wave.
+// rs_rollout16.hpp -- K6: the fused collector with 16 envs per wave.
 //
-// v1 (rs_rollout_kernel) gives a wave 64 envs: 4096 envs are 64 waves on 64 of the 256 CUs, and every lock-step
-// pays 304 MFMAs of 64 cycles on one SIMD.  v2 gives a wave 16 envs: 256 waves (every CU busy), the MLP runs on
-// v_mfma_f32_16x16x4_f32 tiles (152 MFMAs of 32 cycles per lock-step), and the env step -- a latency-bound scalar
-// f64 chain whose cost does not depend on how many lanes run it -- is paid once per 16 envs on 4x as many CUs.
+// A wave owns 16 envs: 4096 envs are 256 waves (every CU busy), the MLP runs on v_mfma_f32_16x16x4_f32 tiles (152
+// MFMAs of 32 cycles per lock-step), and the env step -- a latency-bound scalar f64 chain whose cost does not depend on
+// how many lanes run it -- is paid once per 16 envs.  (A 64-envs-per-wave layout was measured in round 1: 64 waves on 64
+// of the 256 CUs and 304 MFMAs of 64 cycles per lock-step on one SIMD: slower.)
 //
 // Lane mapping: lane l = (j = l&15, g = l>>4).  Env slot j of the wave is env n = 16*block + j; its state and all
 // per-env logic live in lane (j, 0).  For the MLP the four lanes (j, 0..3) share sample j:
@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     int steps = R.steps_in_ep[n];
     float ep_ret = R.ep_ret[n];
     int done_count = 0, oob_count = 0, ep_count = 0;
-    double ep_ret_sum = 0.0, ep_len_sum = 0.0;
+    double ep_ret_sum = 0.0, ep_len_sum = 0.0, ep_ret_sq = 0.0;
+    float ep_ret_max = -INFINITY, ep_ret_min = INFINITY;
     const uint32_t k0 = P.seed, k1 = P.env_id_base + (uint32_t)n;
 
     float xo[RS_IN_PAD], xs[RS_IN_PAD];
@@ -225,7 +226,11 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
         if (own) {
             R.cut[row] = cut ? 1 : 0;
             R.last_val[row] = (cut && boot) ? vb : 0.0f;
-            if (over) { ep_ret_sum += (double)ep_ret; ep_len_sum += (double)steps; ep_count += 1; }
+            if (over) {
+                ep_ret_sum += (double)ep_ret; ep_len_sum += (double)steps; ep_count += 1;
+                ep_ret_sq += (double)ep_ret * (double)ep_ret;
+                ep_ret_max = fmaxf(ep_ret_max, ep_ret); ep_ret_min = fminf(ep_ret_min, ep_ret);
+            }
             if (cut) {
                 if (ended) P.epoch_end[n] = 1;
                 W.reset();
@@ -256,5 +261,6 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
         R.ep_ret[n] = ep_ret;
         R.done_count[n] = done_count; R.oob_count[n] = oob_count; R.ep_count[n] = ep_count;
         R.ep_ret_sum[n] = ep_ret_sum; R.ep_len_sum[n] = ep_len_sum;
+        R.ep_ret_sq_sum[n] = ep_ret_sq; R.ep_ret_max[n] = ep_ret_max; R.ep_ret_min[n] = ep_ret_min;
     }
 }

@@ -12,6 +12,7 @@ librs_hip.so through the C ABI (include/radsearch.h).
 """
 import ctypes as C
 import math
+import sys
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple, Union
 
@@ -298,22 +299,24 @@ class RadSearch:
         return observation, reward, terminal, infos
 
     def step(self, action: Optional[Union[int, Dict[int, int]]] = None):
+        """rad_search_env.py:443-728.  dict -> every agent its own action, collision rule applied (:645-659); int -> the
+        same action for every agent WITHOUT the collision rule (:676-690; -1 == idle 8); None (or an empty dict) -> no
+        move, a fresh measurement at the current position (:528-567)."""
         assert action is None or type(action) == int or type(action) == dict, "Action not integer or a dictionary of actions."
         A = self.number_agents
-        if action is None:
-            raise NotImplementedError("step(None) is only used inside reset() (rad_search_env.py:794); call reset()")
         if type(action) is int:
             if action == -1:
                 action = 8
             assert 0 <= action <= 8
-            acts = [action] * A
             if A > 1:
-                raise NotImplementedError("single-int action for several agents bypasses the collision rule "
-                                          "(rad_search_env.py:676-690); pass a dict")
-        else:
+                print("WARNING: Passing single action to mutliple agents during step!", file=sys.stderr)
+            acts = [16 + action] * A                    # C ABI: 16 + a = the single-int form
+        elif type(action) is dict and action:
             for i, a in action.items():
-                assert 0 <= a <= 8
+                assert 0 <= action[i] <= 8
             acts = [action[i] for i in range(A)]
+        else:
+            acts = [9] * A                              # C ABI: 9 = step(None)
         a_t = torch.tensor(acts, dtype=torch.int8, device=self._vec.device).view(1, A)
         return self._tuple(self._vec.step(a_t))
 

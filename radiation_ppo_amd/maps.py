@@ -126,11 +126,12 @@ class ConvTrunk(torch.autograd.Function):
         mask = torch.empty(S, 169, dtype=torch.int16, device=maps.device) if train else None
         stream = torch.cuda.current_stream(maps.device).cuda_stream
         wt = torch.empty(lib.rs_cnn_trunk_scratch_floats(6 if agent >= 0 else 4), dtype=torch.float32, device=maps.device)
-        _lib.check(lib.rs_cnn_trunk_forward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
-                                            pcells.data_ptr() if agent >= 0 else None, A, agent, S, w1c.data_ptr(), b1c.data_ptr(),
-                                            w2c.data_ptr(), b2c.data_ptr(), a2.data_ptr(), p1.data_ptr() if train else None,
-                                            amax.data_ptr() if train else None, mask.data_ptr() if train else None, wt.data_ptr(),
-                                            stream), "rs_cnn_trunk_forward")
+        with _lib.timed("rs_cnn_trunk_forward_train" if train else "rs_cnn_trunk_forward"):
+            _lib.check(lib.rs_cnn_trunk_forward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
+                                                pcells.data_ptr() if agent >= 0 else None, A, agent, S, w1c.data_ptr(), b1c.data_ptr(),
+                                                w2c.data_ptr(), b2c.data_ptr(), a2.data_ptr(), p1.data_ptr() if train else None,
+                                                amax.data_ptr() if train else None, mask.data_ptr() if train else None, wt.data_ptr(),
+                                                stream), "rs_cnn_trunk_forward")
         if train:
             ctx.save_for_backward(maps, cells if agent >= 0 else maps, pcells if agent >= 0 else maps, w2c, mask, p1, amax)
             ctx.agent, ctx.A, ctx.cin = agent, A, (6 if agent >= 0 else 4)
@@ -145,12 +146,12 @@ class ConvTrunk(torch.autograd.Function):
         rows, row = lib.rs_cnn_trunk_slab_rows(S, cin), lib.rs_cnn_trunk_slab_row(cin)
         slab = torch.empty(rows, row, dtype=torch.float32, device=maps.device)
         stream = torch.cuda.current_stream(maps.device).cuda_stream
-        _lib.check(lib.rs_cnn_trunk_backward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
-                                             pcells.data_ptr() if agent >= 0 else None, ctx.A, agent, S, w2c.data_ptr(),
-                                             da2.data_ptr(), mask.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(),
-                                             torch.empty(lib.rs_cnn_trunk_scratch_floats(cin), dtype=torch.float32,
-                                                         device=maps.device).data_ptr(), stream),
-                   "rs_cnn_trunk_backward")
+        wt = torch.empty(lib.rs_cnn_trunk_scratch_floats(cin), dtype=torch.float32, device=maps.device)
+        with _lib.timed("rs_cnn_trunk_backward"):
+            _lib.check(lib.rs_cnn_trunk_backward(maps.data_ptr(), cells.data_ptr() if agent >= 0 else None,
+                                                 pcells.data_ptr() if agent >= 0 else None, ctx.A, agent, S, w2c.data_ptr(),
+                                                 da2.data_ptr(), mask.data_ptr(), p1.data_ptr(), amax.data_ptr(), slab.data_ptr(),
+                                                 wt.data_ptr(), stream), "rs_cnn_trunk_backward")
         g = slab.sum(dim=0)
         n1 = 8 * cin * 9
         return (None, None, None, None, g[:n1].view(8, cin, 3, 3), g[n1:n1 + 8], g[n1 + 8:n1 + 8 + 1152].view(16, 8, 3, 3),

@@ -92,9 +92,9 @@ class FusedPPOGrad:
         self.lib = _lib.load()
         self.ac = ac
         dev = next(ac.parameters()).device
-        # one flat bucket for the data-parallel exchange: [gradients | the 5 loss statistics as float32]
-        self.bucket = torch.zeros(N_PARAMS + 8, dtype=torch.float32, device=dev)
-        self.grads = self.bucket[:N_PARAMS]
+        # one flat float32 bucket = all gradients (the data-parallel exchange reduces it in ONE collective); the five
+        # loss statistics stay float64 end to end so the KL early-stop decision is bit-identical for 1 and N ranks
+        self.grads = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(5, dtype=torch.float64, device=dev)
         self.ws = torch.empty(self.lib.rs_ppo_grad_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
         self._ws_ptr = self.ws.data_ptr() + (-self.ws.data_ptr()) % 256
@@ -105,7 +105,6 @@ class FusedPPOGrad:
         self.v = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)       # Adam exp_avg_sq
         self.state = torch.zeros(8, dtype=torch.float64, device=dev)          # rs_update_state (56 bytes used)
         self.state_i32 = self.state.view(torch.int32)                         # [adam_step, stopped, iters, pad, ...]
-        self.launch_events = None        # list -> every rs_ppo_grad launch is bracketed by HIP events on its stream (bench.py)
         self.views = []
         o = 0
         for p in order:
@@ -138,25 +137,19 @@ class FusedPPOGrad:
         b = _lib.RsPpoBatch(X.data_ptr(), act.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp_old.data_ptr(), w.data_ptr(),
                             X.shape[0], clip_ratio, alpha, vf_coef)
         pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
-        ev = None
-        if self.launch_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
-                                        self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
-                                        torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
-        if ev is not None:
-            ev[1].record()
-            self.launch_events.append(ev)
+        with _lib.timed("rs_ppo_grad"):
+            _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
+                                            self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
+                                            torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
         return self.stats, self.grads
 
     def allreduce(self) -> None:
-        """mpi_avg_grads (ppo.py:1256) + mpi_avg(kl) (:1250) as ONE RCCL all-reduce per Adam step: the statistics ride
-        in the tail of the gradient bucket (xGMI all-reduces of this size are latency bound, so the count matters,
-        not the bytes).  The loss weights already carry 1/(global env count): SUM over ranks = the reference's average."""
-        self.bucket[N_PARAMS:N_PARAMS + 5] = self.stats
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
-        self.stats.copy_(self.bucket[N_PARAMS:N_PARAMS + 5])
+        """mpi_avg_grads (ppo.py:1256) + mpi_avg(kl) (:1250): one RCCL all-reduce of the flat gradient bucket and one of
+        the five float64 statistics per Adam step (xGMI all-reduces of this size are latency bound: the count matters,
+        not the bytes).  The loss weights already carry 1/(global env count): SUM over ranks = the reference's average.
+        After the KL early stop rs_ppo_grad publishes zeros, so the remaining (no-op) iterations reduce zeros."""
+        dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        dist.all_reduce(self.stats, op=dist.ReduceOp.SUM)
 
     def assign_grads(self) -> None:
         for p, g in self.views:
@@ -358,10 +351,33 @@ class VecAgentPPO:
                             kl_divergence=last[0], Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
 
     def save(self, path: str) -> None:
+        """FF_core.PPO.save (FF_core.py:257-258): the network's state_dict (keys actor.N.*, critic.N.*)."""
         torch.save(self.agent.state_dict(), path)
 
     def load(self, path: str) -> None:
         self.agent.load_state_dict(torch.load(path, map_location=self.device))
+
+    def resume_state(self) -> Dict[str, Any]:
+        """Everything a resumed run needs beyond the weights (absent in the reference): Adam moments and step
+        count of the device-side optimiser (or the torch optimiser of the autograd path) and the LR-schedule position."""
+        st: Dict[str, Any] = dict(model=self.agent.state_dict(), epochs_done=self.epochs_done,
+                                  pi_optimizer=self.pi_optimizer.state_dict(), pi_scheduler=self.pi_scheduler.state_dict())
+        if self._fused is not None:
+            f = self._fused
+            st["fused"] = dict(m=f.m.clone(), v=f.v.clone(), adam_step=int(f.state_i32[0].item()))
+        return st
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        self.agent.load_state_dict(st["model"])
+        self.epochs_done = int(st["epochs_done"])
+        self.pi_optimizer.load_state_dict(st["pi_optimizer"])
+        self.pi_scheduler.load_state_dict(st["pi_scheduler"])
+        if "fused" in st:
+            if self._fused is None:
+                self._fused = FusedPPOGrad(self.agent)
+            f = self._fused
+            f.m.copy_(st["fused"]["m"]); f.v.copy_(st["fused"]["v"])
+            f.state_i32[0] = int(st["fused"]["adam_step"])
 
 
 def normalize_advantages(adv: torch.Tensor) -> torch.Tensor:
@@ -379,6 +395,41 @@ def normalize_advantages(adv: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(sq, op=dist.ReduceOp.SUM)
     std = torch.sqrt(sq / n).float()
     return (adv - mean) / std
+
+
+class EpochStats:
+    """What train() hands its loggers per epoch and agent id (train.py:386-398, :494-501, :519-526), accumulated on the
+    device over all envs: out-of-bounds and terminal counters, and n / sum / sum of squares / max / min of the returns
+    and the lengths of the episodes that ended."""
+
+    def __init__(self, A: int, device):
+        f64 = dict(dtype=torch.float64, device=device)
+        self.oob = torch.zeros(A, **f64)
+        self.done = torch.zeros(A, **f64)
+        self.ep_cnt = torch.zeros((), **f64)
+        self.ep_len = torch.zeros((), **f64)
+        self.ret_sum = torch.zeros(A, **f64)
+        self.ret_sq = torch.zeros(A, **f64)
+        self.ret_max = torch.full((A,), float("-inf"), **f64)
+        self.ret_min = torch.full((A,), float("inf"), **f64)
+
+    def step(self, out_of_bounds: torch.Tensor, done: torch.Tensor) -> None:
+        self.oob += out_of_bounds.double().sum(dim=0)                        # [N,A] -> per agent id
+        self.done += done.double().sum(dim=0)                                # terminals[id] (the env latch as agent id saw it)
+
+    def episodes(self, ep_ret: torch.Tensor, steps_in_ep: torch.Tensor, over: torch.Tensor) -> None:
+        m = over.unsqueeze(1)
+        r = ep_ret.double()
+        self.ret_sum += (r * m).sum(dim=0)
+        self.ret_sq += (r * r * m).sum(dim=0)
+        self.ret_max = torch.maximum(self.ret_max, torch.where(m, r, torch.full_like(r, float("-inf"))).max(dim=0).values)
+        self.ret_min = torch.minimum(self.ret_min, torch.where(m, r, torch.full_like(r, float("inf"))).min(dim=0).values)
+        self.ep_len += (steps_in_ep.double() * over).sum()
+        self.ep_cnt += over.double().sum()
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        return dict(DoneCount=self.done, OutOfBound=self.oob, EpCount=self.ep_cnt, EpLenSum=self.ep_len, EpRetSum=self.ret_sum,
+                    EpRetSqSum=self.ret_sq, EpRetMax=self.ret_max, EpRetMin=self.ret_min)
 
 
 class Collector:
@@ -425,11 +476,7 @@ class Collector:
             self.start()
         env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
         dev = env.device
-        done_count = torch.zeros(N, dtype=torch.int32, device=dev)
-        oob_count = torch.zeros(N, A, dtype=torch.int32, device=dev)
-        ep_ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        ep_len_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        ep_cnt = torch.zeros((), dtype=torch.float64, device=dev)
+        acc = EpochStats(A, dev)
         for t in range(T):
             x = self._x(self.obs)                                            # train.py:334-341
             env.action_uniforms(self._u)
@@ -447,9 +494,8 @@ class Collector:
             buf.rew[t] = r_used
             self.ep_ret += r_used
             self.steps_in_ep += 1
-            oob_count += info["out_of_bounds"].int()
             terminal = done.bool().any(dim=1)                                       # train.py:387-391
-            done_count += terminal.int()
+            acc.step(info["out_of_bounds"], done)
             timeout = self.steps_in_ep == L                                  # train.py:394-405
             episode_over = terminal | timeout
             epoch_ended = t == T - 1
@@ -463,10 +509,7 @@ class Collector:
             for a, ag in self.agents.items():
                 vb = ag.agent.critic(xb[:, a]).squeeze(-1)
                 buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
-            # episode bookkeeping (train.py:494-501)
-            ep_ret_sum += (self.ep_ret[:, 0].double() * episode_over).sum()
-            ep_len_sum += (self.steps_in_ep.double() * episode_over).sum()
-            ep_cnt += episode_over.double().sum()
+            acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)       # train.py:494-501
             if epoch_ended:
                 env.set_epoch_end()                                          # train.py:482-484
             self.stat.reset(cut)                                             # train.py:504-509
@@ -476,8 +519,7 @@ class Collector:
             self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
             self.stat.update(self.obs[..., 0], mask=cut)                     # train.py:542-548
         buf.finish(self.agents[0].gamma, self.agents[0].lam)
-        return dict(DoneCount=done_count.sum(), OutOfBound=oob_count.sum(), EpRetSum=ep_ret_sum, EpLenSum=ep_len_sum,
-                    EpCount=ep_cnt)
+        return acc.result()
 
     def update(self) -> Dict[int, UpdateResult]:
         return ppo_update_from_buffer(self)
@@ -508,13 +550,17 @@ class FusedCollector:
         self.ep_count = torch.zeros(N, dtype=torch.int32, device=dev)
         self.ep_ret_sum = torch.zeros(N, **f64)
         self.ep_len_sum = torch.zeros(N, **f64)
+        self.ep_ret_sq = torch.zeros(N, **f64)
+        self.ep_ret_max = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.ep_ret_min = torch.zeros(N, dtype=torch.float32, device=dev)
         b = self.buf
         self._args = _lib.RsRolloutArgs(
             self.T, self.L, b.obs.data_ptr(), b.act.data_ptr(), b.logp.data_ptr(), b.val.data_ptr(), b.rew.data_ptr(),
             b.last_val.data_ptr(), b.cut.data_ptr(), b.source_tar.data_ptr(), self.cur_obs.data_ptr(),
             self.w_count.data_ptr(), self.w_mean.data_ptr(), self.w_sq.data_ptr(), self.w_std.data_ptr(),
             self.steps_in_ep.data_ptr(), self.ep_ret.data_ptr(), self.done_count.data_ptr(), self.oob_count.data_ptr(),
-            self.ep_ret_sum.data_ptr(), self.ep_len_sum.data_ptr(), self.ep_count.data_ptr())
+            self.ep_ret_sum.data_ptr(), self.ep_len_sum.data_ptr(), self.ep_count.data_ptr(),
+            self.ep_ret_sq.data_ptr(), self.ep_ret_max.data_ptr(), self.ep_ret_min.data_ptr())
         self.started = False
 
     def start(self) -> None:
@@ -533,11 +579,15 @@ class FusedCollector:
             self.start()
         ac = self.agents[0].agent
         pa, pc = mlp_params(ac.actor), mlp_params(ac.critic)
-        _lib.check(self.env.lib.rs_rollout(self.env._h, C.byref(pa), C.byref(pc), C.byref(self._args), self.env._stream()),
-                   "rs_rollout")
-        self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
-        return dict(DoneCount=self.done_count.sum(), OutOfBound=self.oob_count.sum(), EpRetSum=self.ep_ret_sum.sum(),
-                    EpLenSum=self.ep_len_sum.sum(), EpCount=self.ep_count.double().sum())
+        with _lib.timed("rs_rollout"):
+            _lib.check(self.env.lib.rs_rollout(self.env._h, C.byref(pa), C.byref(pc), C.byref(self._args), self.env._stream()),
+                       "rs_rollout")
+        with _lib.timed("rs_gae"):
+            self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        one = lambda t: t.double().sum().view(1)
+        return dict(DoneCount=one(self.done_count), OutOfBound=one(self.oob_count), EpCount=self.ep_count.double().sum(),
+                    EpLenSum=self.ep_len_sum.sum(), EpRetSum=one(self.ep_ret_sum), EpRetSqSum=one(self.ep_ret_sq),
+                    EpRetMax=self.ep_ret_max.double().max().view(1), EpRetMin=self.ep_ret_min.double().min().view(1))
 
     def update(self) -> Dict[int, UpdateResult]:
         return ppo_update_from_buffer(self)

@@ -11,6 +11,7 @@ Mirrors (paths relative to the reference root):
 The location-prediction map (PFGRU) is not built: channel 0 stays empty unless the caller
 supplies predictions.
 """
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -19,7 +20,7 @@ import torch.distributed as dist
 from . import _lib
 from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps
-from .ppo import RolloutBuffer, UpdateResult, _world, normalize_advantages
+from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
 
 
 class CNNAgentPPO:
@@ -28,6 +29,7 @@ class CNNAgentPPO:
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, GlobalCritic: Optional[CNNCritic] = None,
                  GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 524288, **unused: Any):
         self.id = id
+        self.map_dim = tuple(map_dim)
         self.device = torch.device(device)
         self.gamma, self.lam, self.alpha = gamma, lam, alpha
         self.clip_ratio, self.target_kl = clip_ratio, target_kl
@@ -134,7 +136,28 @@ class CNNAgentPPO:
                             Entropy=last[1], ClipFrac=last[2], LocLoss=0.0)
 
     def save(self, path: str) -> None:
-        torch.save({"actor": self.pi.state_dict(), "critic": self.critic.state_dict()}, path)
+        """CNNBase.save (RADTEAM_core.py:1904-1943): `<path>/actor.pt` and `<path>/critic.pt` hold the modules' state_dicts
+        (keys actor.N.* / critic.N.*, :1170-1180, :1331-1342), so saved models interchange with the reference."""
+        os.makedirs(path, exist_ok=True)
+        torch.save(self.pi.state_dict(), os.path.join(path, "actor.pt"))
+        torch.save(self.critic.state_dict(), os.path.join(path, "critic.pt"))
+
+    def load(self, path: str) -> None:
+        """CNNBase.load (:1945-1953)."""
+        for mod, name in ((self.pi, "actor.pt"), (self.critic, "critic.pt")):
+            f = os.path.join(path, name)
+            assert os.path.isfile(f), "Model does not exist"
+            mod.load_state_dict(torch.load(f, map_location=self.device))
+
+    def resume_state(self) -> Dict[str, Any]:
+        return dict(actor=self.pi.state_dict(), critic=self.critic.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
+                    critic_optimizer=self.critic_optimizer.state_dict(), pi_scheduler=self.pi_scheduler.state_dict(),
+                    critic_scheduler=self.critic_scheduler.state_dict())
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        self.pi.load_state_dict(st["actor"]); self.critic.load_state_dict(st["critic"])
+        self.pi_optimizer.load_state_dict(st["pi_optimizer"]); self.critic_optimizer.load_state_dict(st["critic_optimizer"])
+        self.pi_scheduler.load_state_dict(st["pi_scheduler"]); self.critic_scheduler.load_state_dict(st["critic_scheduler"])
 
 
 class CNNCollector:
@@ -148,6 +171,14 @@ class CNNCollector:
         dev = env.device
         self.maps = HeatMaps(env, steps_per_episode, enforce_boundaries=bool(env.cfg.enforce_grid_boundaries))
         X, Y = self.maps.map_dimensions
+        if (X, Y) != (27, 27):
+            # RADTEAM_core.py:1727-1738: without enforced walls the maps grow to 147 x 147; the HIP trunk (csrc/rs_cnn.hip)
+            # is built for the walls-enforced 27 x 27 case the reference's CLIs train with (main.py:311-316)
+            raise NotImplementedError(f"heat maps of {X} x {Y} cells: the CNN trunk kernels are built for 27 x 27 maps "
+                                      "(enforce_grid_boundaries=True with the default 2700 cm bbox and (200, 500) observation area)")
+        for ag in agents.values():
+            if tuple(ag.map_dim) != (X, Y):
+                raise ValueError(f"agent {ag.id} was built for {ag.map_dim} maps, the environment produces {(X, Y)}")
         self.buf = RolloutBuffer(self.T, self.N, self.A, _lib.RS_OBS_DIM, dev)
         # per step only the four shared maps and the cell indices are stored; actor stacks are rebuilt on demand
         self.shared = torch.zeros(self.T, self.N, 4, X, Y, dtype=torch.float32, device=dev)
@@ -188,11 +219,7 @@ class CNNCollector:
             self.start()
         env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
         dev = env.device
-        done_count = torch.zeros(N, dtype=torch.int32, device=dev)
-        oob_count = torch.zeros(N, A, dtype=torch.int32, device=dev)
-        ep_ret_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        ep_len_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        ep_cnt = torch.zeros((), dtype=torch.float64, device=dev)
+        acc = EpochStats(A, dev)
         self.complete_len.zero_()
         for t in range(T):
             critic, cells, pcells = self._round()
@@ -215,9 +242,8 @@ class CNNCollector:
             buf.rew[t] = r_used
             self.ep_ret += r_used
             self.steps_in_ep += 1
-            oob_count += info["out_of_bounds"].int()
             terminal = done.bool().any(dim=1)
-            done_count += terminal.int()
+            acc.step(info["out_of_bounds"], done)
             timeout = self.steps_in_ep == L
             episode_over = terminal | timeout
             epoch_ended = t == T - 1
@@ -233,9 +259,7 @@ class CNNCollector:
                 if not ag.global_critic or vb is None:
                     vb = ag._values((critic_b,))
                 buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
-            ep_ret_sum += (self.ep_ret[:, 0].double() * episode_over).sum()
-            ep_len_sum += (self.steps_in_ep.double() * episode_over).sum()
-            ep_cnt += episode_over.double().sum()
+            acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
             self.complete_len = torch.where(episode_over, torch.full_like(self.complete_len, t + 1), self.complete_len)
             if epoch_ended:
                 env.set_epoch_end()
@@ -245,8 +269,7 @@ class CNNCollector:
             self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
             self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
         buf.finish(self.agents[0].gamma, self.agents[0].lam)
-        return dict(DoneCount=done_count.sum(), OutOfBound=oob_count.sum(), EpRetSum=ep_ret_sum, EpLenSum=ep_len_sum,
-                    EpCount=ep_cnt)
+        return acc.result()
 
     def update(self) -> Dict[int, UpdateResult]:
         buf, T, N = self.buf, self.T, self.N

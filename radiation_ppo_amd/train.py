@@ -4,65 +4,48 @@
 `env` may be a radiation_ppo_amd.envs.RadSearchVec (N envs) or the 1-env RadSearch adapter.  The
 epoch x step double loop, the episode/epoch cut rules, the bootstrap rule, the epoch_end hand-shake,
 the update and the logger columns follow train.py:321-627; the per-step work runs batched on the
-device (radiation_ppo_amd.ppo.Collector / FusedCollector).  With torch.distributed initialised
-(one process per GPU, backend "nccl" = RCCL) each rank owns a shard of the envs and gradients, the
-KL estimate and the advantage statistics are all-reduced (the reference's mpi_avg_grads /
-mpi_avg / mpi_statistics_scalar call sites, ppo.py:445,1250,1256).
+device (radiation_ppo_amd.ppo.Collector / FusedCollector, radiation_ppo_amd.ppo_cnn.CNNCollector).  With
+torch.distributed initialised (one process per GPU, backend "nccl" = RCCL) each rank owns a shard of the
+envs and gradients, the KL estimate and the advantage statistics are all-reduced (the reference's
+mpi_avg_grads / mpi_avg / mpi_statistics_scalar call sites, ppo.py:445,1250,1256).
+
+Logging and checkpoints are the reference's (radiation_ppo_amd.logger.EpochLogger; progress.txt columns of
+train.py:605-627 with two throughput columns appended; CNN models as <agent dir>/actor.pt + critic.pt,
+RADTEAM_core.py:1904-1943; the MLP as <agent dir>/pyt_save/model.pt, epoch_logger.py:216-284) plus what the
+reference lacks for a true resume: optimiser moments, step counts and the LR-schedule position (resume.pt).
 """
-import json
+import math
 import os
 import time
 from dataclasses import dataclass, field
-from typing import Any, Dict, Optional, Union
+from typing import Any, Dict, Union
 
 import torch
 import torch.distributed as dist
 
 from .envs import RadSearch, RadSearchVec
+from .logger import EpochLogger, convert_json, setup_logger_kwargs
+from .maps import CNNCritic
 from .ppo import Collector, FusedCollector, VecAgentPPO
 from .ppo_cnn import CNNAgentPPO, CNNCollector
-from .maps import CNNCritic
 
-# progress.txt columns of the reference (train.py:605-627) + throughput columns of this build
-COLUMNS = ["AgentID", "Epoch", "AverageVVals", "StdVVals", "MaxVVals", "MinVVals", "TotalEnvInteracts", "loss_policy",
+# progress.txt columns of the reference (train.py:605-627, epoch_logger.py:393-398) + throughput columns of this build
+COLUMNS = ["AgentID", "Epoch", "MeanVVals", "StdVVals", "MaxVVals", "MinVVals", "TotalEnvInteracts", "loss_policy",
            "loss_critic", "loss_predictor", "LocLoss", "Entropy", "kl_divergence", "ClipFrac", "OutOfBound",
-           "stop_iteration", "AverageEpRet", "DoneCount", "EpLen", "Time", "EnvStepsPerSec", "PPOItersPerSec"]
-
-
-class ProgressLogger:
-    """Tab-separated progress.txt with the reference's column names (epoch_logger.py:286-337)."""
-
-    def __init__(self, output_dir: Optional[str], exp_name: str = ""):
-        self.rows = []
-        self.file = None
-        if output_dir:
-            os.makedirs(output_dir, exist_ok=True)
-            self.file = open(os.path.join(output_dir, "progress.txt"), "w")
-            self.file.write("\t".join(COLUMNS) + "\n")
-        self.output_dir = output_dir
-
-    def dump(self, row: Dict[str, Any]) -> None:
-        self.rows.append(row)
-        if self.file:
-            self.file.write("\t".join(str(row.get(c, "")) for c in COLUMNS) + "\n")
-            self.file.flush()
-
-    def save_config(self, cfg: Dict[str, Any]) -> None:
-        if self.output_dir:
-            with open(os.path.join(self.output_dir, "config.json"), "w") as f:
-                json.dump(cfg, f, indent=4, sort_keys=True, default=str)
+           "stop_iteration", "MeanEpRet", "StdEpRet", "MaxEpRet", "MinEpRet", "DoneCount", "EpLen", "Time",
+           "EnvStepsPerSec", "PPOItersPerSec"]
 
 
 @dataclass
 class train_PPO:
-    """Signature of algos/multiagent/train.py:77-154."""
+    """Signature and defaults of algos/multiagent/train.py:77-154."""
     env: Union[RadSearchVec, RadSearch]
     logger_kwargs: Dict[str, Any] = field(default_factory=dict)
     ppo_kwargs: Dict[str, Any] = field(default_factory=dict)
     seed: int = 0
     number_of_agents: int = 1
-    actor_critic_architecture: str = "ff"
-    global_critic_flag: bool = False
+    actor_critic_architecture: str = "cnn"
+    global_critic_flag: bool = True
     steps_per_epoch: int = 480
     steps_per_episode: int = 120
     total_epochs: int = 3000
@@ -75,13 +58,42 @@ class train_PPO:
     episode_count: int = 0
     DEBUG: bool = False
 
+    def _make_loggers(self) -> None:
+        """train.py:166-190.  logger_kwargs is either the reference's {exp_name, seed, data_dir, env_name} (a parent
+        "general" directory with config.json + one `<id>_agent_<exp_name>` directory per agent) or {"output_dir": d}
+        (agent directories d/<id>_agent); empty: nothing is written (rows stay available in `loggers[i].rows`)."""
+        kw = self.logger_kwargs or {}
+        write = self.rank == 0
+        cfg = convert_json(dict(ppo_kwargs=self.ppo_kwargs, seed=self.seed, steps_per_epoch=self.steps_per_epoch,
+                                steps_per_episode=self.steps_per_episode, total_epochs=self.total_epochs,
+                                number_of_agents=self.number_of_agents, actor_critic_architecture=self.actor_critic_architecture,
+                                global_critic_flag=self.global_critic_flag, save_freq=self.save_freq,
+                                num_envs=self.vec.num_envs * self.world, world_size=self.world))
+        self.parent_logger = None
+        if write and "data_dir" in kw:
+            pk = setup_logger_kwargs(exp_name="general", seed=kw.get("seed"), data_dir=kw["data_dir"], env_name=kw.get("env_name"))
+            self.parent_logger = EpochLogger(**pk)
+            self.parent_logger.save_config(cfg)
+        self.loggers = {}
+        for i in range(self.number_of_agents):
+            if write and "data_dir" in kw:
+                lk = setup_logger_kwargs(exp_name=f"{i}_agent_{kw.get('exp_name', '')}", seed=kw.get("seed"),
+                                         data_dir=kw["data_dir"], env_name=kw.get("env_name"))
+            elif write and kw.get("output_dir"):
+                lk = dict(output_dir=os.path.join(str(kw["output_dir"]), f"{i}_agent"), exp_name=kw.get("exp_name"))
+            else:
+                lk = dict(output_dir=None)
+            self.loggers[i] = EpochLogger(**lk)
+        if write and self.parent_logger is None and self.loggers[0].output_dir:
+            self.loggers[0].save_config(cfg)
+
     def __post_init__(self) -> None:
         if self.actor_critic_architecture != "cnn" and self.global_critic_flag:
             raise ValueError("Global critic not supported in RAD-A2C")        # train.py:157-160
         if self.actor_critic_architecture not in ("ff", "mlp", "cnn"):
             raise NotImplementedError(f"architecture {self.actor_critic_architecture!r}: the 2x64 MLP path ('ff', alias "
-                                      "'mlp') and the RAD-TEAM CNN path ('cnn') are built; the GRU/PFGRU cores are SURVEY.md "
-                                      "section 8 rows f1/f2")
+                                      "'mlp') and the RAD-TEAM CNN path ('cnn') are built; the GRU/PFGRU core is SURVEY.md "
+                                      "section 8 row f2")
         if self.render or self.save_gif:
             raise NotImplementedError("rendering is outside the hot path")
         if self.seed:
@@ -90,71 +102,140 @@ class train_PPO:
         assert self.vec.number_agents == self.number_of_agents
         self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        out = self.logger_kwargs.get("output_dir") if self.logger_kwargs else None
-        self.loggers = {i: ProgressLogger(os.path.join(str(out), f"{i}_agent") if (out and self.rank == 0) else None)
-                        for i in range(self.number_of_agents)}
-        if out and self.rank == 0:
-            self.loggers[0].save_config(dict(ppo_kwargs=self.ppo_kwargs, seed=self.seed,
-                                             steps_per_epoch=self.steps_per_epoch, steps_per_episode=self.steps_per_episode,
-                                             number_of_agents=self.number_of_agents, num_envs=self.vec.num_envs * self.world))
+        self._make_loggers()
         kw = dict(self.ppo_kwargs)
         kw.pop("actor_critic_architecture", None)
         kw.setdefault("steps_per_epoch", self.steps_per_epoch)
         kw.setdefault("steps_per_episode", self.steps_per_episode)
         kw.setdefault("number_of_agents", self.number_of_agents)
+        self.start_time = time.time()
+        self.epochs_done = 0
         if self.actor_critic_architecture == "cnn":
             gc = gco = None
             if self.global_critic_flag:                                        # train.py:191-206
                 gc = CNNCritic().to(self.vec.device)
                 gco = torch.optim.Adam(gc.parameters(), lr=kw.get("critic_learning_rate", 1e-3))
             kw.pop("GlobalCriticOptimizer", None)
+            self.collector = None
             self.agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, device=self.vec.device, **kw)
                            for i in range(self.number_of_agents)}
             for ag in self.agents.values():
                 ag.sync_params()
             self.collector = CNNCollector(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
                                           global_critic_flag=self.global_critic_flag)
-            self.start_time = time.time()
             return
         self.agents = {i: VecAgentPPO(id=i, actor_critic_architecture=self.actor_critic_architecture,
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}
-        for ag in self.agents.values():
+        for i, ag in self.agents.items():
             ag.sync_params()                                                   # train.py:248-256
+            self.loggers[i].setup_pytorch_saver(ag.agent)                      # train.py:221-226
         fusable = (self.number_of_agents == 1 and self.vec.num_envs % 16 == 0 and self.vec.cfg.geom_group_size == 1
                    and not self.global_critic_flag)
         cls = FusedCollector if fusable else Collector      # one launch per epoch (rs_rollout) when the config allows
         self.collector = cls(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
                              global_critic_flag=self.global_critic_flag)
-        self.start_time = time.time()
 
+    # ------------------------------------------------------------------ checkpoints
+    def save(self) -> None:
+        """train.py:552-561: every save_freq epochs, BEFORE the epoch's update, the reference's model files: CNN agents
+        <agent dir>/actor.pt + critic.pt (RADTEAM_core.py:1904-1943), the MLP <agent dir>/pyt_save/model.pt (epoch_logger.py:216-284)."""
+        for i, ag in self.agents.items():
+            d = self.loggers[i].output_dir
+            if not d:
+                continue
+            if self.actor_critic_architecture == "cnn":
+                ag.save(d)
+            else:
+                self.loggers[i].save_state({}, None)
+
+    def save_resume(self) -> None:
+        """After the update of the same epochs: <agent dir>/resume.pt = weights + optimiser moments + step counts + LR-schedule
+        position + the epoch counter (what the reference lacks for a true resume)."""
+        for i, ag in self.agents.items():
+            d = self.loggers[i].output_dir
+            if d:
+                torch.save(dict(agent=ag.resume_state(), epochs_done=self.epochs_done, torch_rng=torch.get_rng_state()),
+                           os.path.join(d, "resume.pt"))
+
+    def load(self, directory: str) -> None:
+        """Resume from agent directories `<directory>/<id>_agent...` written by save() (weights, optimiser moments, step counts,
+        LR-schedule position).  The env's Philox streams are keyed by (seed, env id, episode): nothing else to restore."""
+        for i, ag in self.agents.items():
+            cands = [os.path.join(directory, n) for n in sorted(os.listdir(directory)) if n.startswith(f"{i}_agent")]
+            hits = ([c for c in cands if os.path.exists(os.path.join(c, "resume.pt"))]
+                    or [os.path.join(c, s) for c in cands for s in sorted(os.listdir(c))
+                        if os.path.exists(os.path.join(c, s, "resume.pt"))])
+            if not hits:
+                raise FileNotFoundError(f"no resume.pt for agent {i} under {directory}")
+            st = torch.load(os.path.join(hits[0], "resume.pt"), map_location=self.vec.device)
+            ag.load_resume_state(st["agent"])
+            self.epochs_done = int(st["epochs_done"])
+
+    # ------------------------------------------------------------------ the loop
     def train(self) -> None:
         """train.py:259-627."""
         self.start_time = time.time()
         T, N = self.steps_per_epoch, self.vec.num_envs * self.world
-        for epoch in range(self.total_epochs):
+        A = self.number_of_agents
+        for epoch in range(self.epochs_done, self.total_epochs):
             t0 = time.time()
             stats = self.collector.collect()
+            saving = self.rank == 0 and ((epoch % self.save_freq == 0) or (epoch == self.total_epochs - 1))
+            if saving:
+                self.save()                                                             # train.py:552-561 (before the update)
             results = self.collector.update()
-            if (epoch % self.save_freq == 0) or (epoch == self.total_epochs - 1):      # train.py:552-561
-                if self.rank == 0 and self.save_path and self.loggers[0].output_dir:
-                    for i, ag in self.agents.items():
-                        ag.save(os.path.join(self.loggers[i].output_dir, "model.pt"))
-            pack = torch.stack([stats["DoneCount"].double(), stats["OutOfBound"].double(), stats["EpRetSum"],
-                                stats["EpLenSum"], stats["EpCount"]])
+            self.epochs_done = epoch + 1
+            if saving:
+                self.save_resume()
+            # ---- epoch statistics: one packed reduction over ranks, one host sync
+            val = self.collector.buf.val.double()                                       # [T, N_local, A]
+            vs = torch.stack([val.sum(dim=(0, 1)), (val * val).sum(dim=(0, 1))])        # [2, A]
+            sums = torch.cat([stats["DoneCount"], stats["OutOfBound"], stats["EpRetSum"], stats["EpRetSqSum"],
+                              stats["EpCount"].view(1), stats["EpLenSum"].view(1), vs.reshape(-1)])
+            mx = torch.cat([stats["EpRetMax"], -stats["EpRetMin"], val.amax(dim=(0, 1)), -val.amin(dim=(0, 1))])
             if self.world > 1:
-                dist.all_reduce(pack)
-            done_c, oob_c, ret_s, len_s, ep_c = pack.tolist()
+                dist.all_reduce(sums)
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sums, mx = sums.tolist(), mx.tolist()
+            k = len(stats["DoneCount"])                 # A, or 1 for the single-agent fused collector
+            done_c, oob_c, ret_s, ret_q = (sums[j * k:(j + 1) * k] for j in range(4))
+            ep_c, len_s = sums[4 * k], sums[4 * k + 1]
+            v_s, v_q = sums[4 * k + 2:4 * k + 2 + A], sums[4 * k + 2 + A:4 * k + 2 + 2 * A]
+            r_max, r_min = mx[:k], [-x for x in mx[k:2 * k]]
+            v_max, v_min = mx[2 * k:2 * k + A], [-x for x in mx[2 * k + A:2 * k + 2 * A]]
             flags = self.vec.error_flags()      # the reference raises on these states (rad_search_env.py:544-565)
             if flags:
                 raise RuntimeError(f"RadSearch env error flags 0x{flags:x} (see RS_ENVERR_* in include/radsearch.h)")
             dt = time.time() - t0
+            n_v = T * N
             for i in self.agents:
-                v = self.collector.buf.val[:, :, i]
-                r = results[i]
-                self.loggers[i].dump(dict(
-                    AgentID=i, Epoch=epoch, AverageVVals=v.mean().item(), StdVVals=v.std().item(), MaxVVals=v.max().item(),
-                    MinVVals=v.min().item(), TotalEnvInteracts=(epoch + 1) * T * N, loss_policy=r.loss_policy,
-                    loss_critic=r.loss_critic, loss_predictor=r.loss_predictor, LocLoss=r.LocLoss, Entropy=r.Entropy,
-                    kl_divergence=r.kl_divergence, ClipFrac=r.ClipFrac, OutOfBound=oob_c / N, stop_iteration=r.stop_iteration,
-                    AverageEpRet=ret_s / max(ep_c, 1.0), DoneCount=done_c, EpLen=len_s / max(ep_c, 1.0),
-                    Time=time.time() - self.start_time, EnvStepsPerSec=T * N / dt, PPOItersPerSec=1.0 / dt))
+                lg, r, j = self.loggers[i], results[i], min(i, k - 1)
+                v_mean = v_s[i] / n_v
+                v_std = math.sqrt(max(v_q[i] / n_v - v_mean * v_mean, 0.0))
+                n_ep = max(ep_c, 1.0)
+                e_mean = ret_s[j] / n_ep
+                e_std = math.sqrt(max(ret_q[j] / n_ep - e_mean * e_mean, 0.0))
+                nan = float("nan")
+                lg.log_tabular("AgentID", i)                                            # train.py:605-627
+                lg.log_tabular("Epoch", epoch)
+                lg.log_stats("VVals", v_mean, v_std, v_max[i], v_min[i], with_min_and_max=True)
+                lg.log_tabular("TotalEnvInteracts", (epoch + 1) * T * N)
+                lg.log_tabular("loss_policy", r.loss_policy)
+                lg.log_tabular("loss_critic", r.loss_critic)
+                lg.log_tabular("loss_predictor", r.loss_predictor)
+                lg.log_tabular("LocLoss", r.LocLoss)
+                lg.log_tabular("Entropy", r.Entropy)
+                lg.log_tabular("kl_divergence", r.kl_divergence)
+                lg.log_tabular("ClipFrac", r.ClipFrac)
+                lg.log_tabular("OutOfBound", oob_c[j] / N)                              # mean over envs of the agent's count
+                lg.log_tabular("stop_iteration", r.stop_iteration)
+                if ep_c > 0:
+                    lg.log_stats("EpRet", e_mean, e_std, r_max[j], r_min[j], with_min_and_max=True)
+                else:
+                    lg.log_stats("EpRet", nan, nan, nan, nan, with_min_and_max=True)
+                lg.log_tabular("DoneCount", done_c[j])
+                lg.log_tabular("EpLen", len_s / n_ep if ep_c > 0 else nan)
+                lg.log_tabular("Time", time.time() - self.start_time)
+                lg.log_tabular("EnvStepsPerSec", T * N / dt)
+                lg.log_tabular("PPOItersPerSec", 1.0 / dt)
+                lg.dump_tabular()

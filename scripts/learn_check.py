@@ -14,7 +14,7 @@ sim = train_PPO(env=env, logger_kwargs={}, ppo_kwargs=dict(observation_space=11,
 sim.train()
 rows = sim.loggers[0].rows
 for r in rows[::max(1, E // 12)] + [rows[-1]]:
-    print(f"epoch {r['Epoch']:3d}  AverageEpRet {r['AverageEpRet']:8.3f}  EpLen {r['EpLen']:6.1f}  DoneCount {r['DoneCount']:7.0f}  "
+    print(f"epoch {r['Epoch']:3d}  MeanEpRet {r['MeanEpRet']:8.3f}  EpLen {r['EpLen']:6.1f}  DoneCount {r['DoneCount']:7.0f}  "
           f"kl {r['kl_divergence']:.4f}  stop {r['stop_iteration']}  Entropy {r['Entropy']:.3f}", flush=True)
 print("per-epoch PPOItersPerSec:", [round(r["PPOItersPerSec"], 1) for r in rows[:3]], "...", [round(r["PPOItersPerSec"], 1) for r in rows[-3:]],
       "collector:", type(sim.collector).__name__)

@@ -44,15 +44,20 @@ if mode == "cnn":
 N, T, L = total_envs // world, 48, 12
 torch.manual_seed(1234)                                              # same initial policy on every rank / world size
 env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)
-agents = {0: VecAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, train_pi_iters=6, actor_learning_rate=3e-3)}
+# "ffstop": a tight KL target so that the early stop (ppo.py:1250-1261) triggers in the MIDDLE of the Adam loop -- the remaining
+# iterations are no-ops that still all-reduce (zeros) on every rank
+kl = 0.002 if mode == "ffstop" else 0.07
+agents = {0: VecAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, train_pi_iters=10 if mode == "ffstop" else 6,
+                         actor_learning_rate=3e-3, target_kl=kl)}
 agents[0].sync_params()
 col = FusedCollector(env, agents, T, L)
 col.collect()
 res = col.update()[0]
 if rank == 0:
     flat = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()]).cpu()
+    f = agents[0]._fused
     torch.save({"params": flat, "kl": res.kl_divergence, "loss": res.loss_policy, "stop": res.stop_iteration,
-                "entropy": res.Entropy}, out)
+                "entropy": res.Entropy, "grads_after": f.grads.cpu(), "stats_after": f.stats.cpu()}, out)
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()

@@ -242,6 +242,65 @@ def gen_env_scenarios():
                                dict(seed=seed, A=A, enforce=int(enforce)))
 
 
+def gen_env_callforms():
+    """The calling conventions of RadSearch.step besides the dict form (rad_search_env.py:616-627, :676-690) for
+    SEVERAL agents: `step(int)` gives every agent the same action WITHOUT the collision rule (agent_step is called with
+    no proposed_coordinates) and `step(None)` re-measures in place (:528-549).  Same row format as env_*.npz plus
+    `form` (0 dict, 1 single int, 2 None)."""
+    from gym_rad_search.envs.rad_search_env import RadSearch
+    for A in (2, 3):
+        for enforce in (True, False):
+            rec = RecordingGenerator(41 + A)
+            env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0, enforce_grid_boundaries=enforce)
+            rows, forms = [], []
+            script = np.random.default_rng(500 + A)
+
+            def record(kind, actions, ret, log_start, form):
+                obs, rew, done, info = ret
+                rows.append(dict(
+                    kind=kind, actions=actions,
+                    obs=[np.asarray(obs[i], dtype=np.float64).tolist() for i in range(A)],
+                    reward=[float(rew["individual_reward"][i]) for i in range(A)],
+                    team=float("nan") if rew["team_reward"] is None else float(rew["team_reward"]),
+                    done_ret=[bool(done[i]) for i in range(A)],
+                    info_oob=[bool(info[i]["out_of_bounds"]) for i in range(A)],
+                    info_oobc=[int(info[i]["out_of_bounds_count"]) for i in range(A)],
+                    info_blocked=[bool(info[i]["blocked"]) for i in range(A)],
+                    src=[float(env.src_coords[0]), float(env.src_coords[1])],
+                    intensity=int(env.intensity), bkg=int(env.bkg_intensity),
+                    draws=rec.log[log_start:], **_snapshot(env, A)))
+                forms.append(form)
+
+            ls = len(rec.log)
+            env.epoch_end = True
+            record("reset", [8] * A, env.reset(), ls, 0)
+            steps_in_ep = 0
+            for t in range(120):
+                ls = len(rec.log)
+                m = t % 6
+                if m in (1, 4):                       # single int: all agents share one cell afterwards, no collision stall
+                    a = int(script.integers(0, 8)) if m == 1 else -1
+                    ret = env.step(a)
+                    record("step", [8 if a == -1 else a] * A, ret, ls, 1)
+                elif m == 3:                          # None: no move, fresh measurement, stale distances
+                    ret = env.step(None)
+                    record("step", [9] * A, ret, ls, 2)
+                else:
+                    acts = [int(script.integers(0, 9)) for _ in range(A)]
+                    ret = env.step({i: acts[i] for i in range(A)})
+                    record("step", acts, ret, ls, 0)
+                steps_in_ep += 1
+                if env.done or steps_in_ep == 25:
+                    ls = len(rec.log)
+                    record("reset", [8] * A, env.reset(), ls, 0)
+                    steps_in_ep = 0
+            path = os.path.join(OUT, f"envforms_a{A}_e{int(enforce)}.npz")
+            _save_env_rows(path, rows, A, dict(seed=41 + A, A=A, enforce=int(enforce)))
+            d = dict(np.load(path).items())
+            d["form"] = np.array(forms, dtype=np.int8)
+            np.savez_compressed(path, **d)
+
+
 def _save_env_rows(path, rows, A, meta):
     n = len(rows)
     f8 = lambda k: np.array([r[k] for r in rows], dtype=np.float64)
@@ -515,26 +574,37 @@ def gen_train_trace():
                 return types.SimpleNamespace(stop_iteration=1, loss_policy=0.0, loss_critic=0.0, loss_predictor=0.0,
                                              kl_divergence=0.0, Entropy=0.0, ClipFrac=0.0, LocLoss=0.0, VarExplain=0.0)
 
-        class Logger:
-            output_dir = None
+        import shutil
+        from pathlib import Path
+        from algos.multiagent.rl_tools.epoch_logger import EpochLogger as RefEpochLogger
+        log_root = tempfile.mkdtemp(prefix="rs_trace_logs_")
+        logger_calls = {i: [] for i in range(A)}
+
+        class Logger(RefEpochLogger):
+            """The reference's OWN EpochLogger (epoch_logger.py:314-403) writing a real progress.txt; every call train()
+            makes on it is recorded so the build's logger can be replayed against the file the reference produced."""
 
             def __init__(self_, id):
+                super().__init__(output_dir=Path(log_root) / f"{id}_agent")
                 self_.id = id
 
             def store(self_, **kw):
                 for k, v in kw.items():
                     if k in ("EpRet", "EpLen", "DoneCount", "OutOfBound"):
                         ev.append(["log", self_.id, k, float(v)])
+                logger_calls[self_.id].append(["store", {k: float(v) for k, v in kw.items()}])
+                super().store(**kw)
 
             def log_tabular(self_, key, val=None, **kw):
                 if key == "TotalEnvInteracts":
                     ev.append(["tabular", self_.id, key, float(val)])
+                logger_calls[self_.id].append(["log_tabular", key, None if val is None else (int(val) if isinstance(val, (int, np.integer)) else float(val)), dict(kw)])
+                super().log_tabular(key, val, **kw)
 
             def dump_tabular(self_):
                 ev.append(["dump", self_.id])
-
-            def log(self_, *a, **k):
-                pass
+                logger_calls[self_.id].append(["dump_tabular"])
+                super().dump_tabular()
 
             def save_state(self_, *a, **k):
                 ev.append(["save", self_.id])
@@ -552,9 +622,16 @@ def gen_train_trace():
         sim.agents = {i: Agent(i) for i in range(A)}
         sim.loggers = {i: Logger(i) for i in range(A)}
         sim.train()
+        progress = {}
+        for i in range(A):
+            sim.loggers[i].output_file.flush()
+            with open(os.path.join(log_root, f"{i}_agent", "progress.txt")) as f:
+                progress[str(i)] = f.read()
+        shutil.rmtree(log_root)
         out[name] = dict(A=A, global_critic=global_critic, T=T, L=L, epochs=epochs, seed=seed, arch=arch,
                          draws=[[k, a0, a1, v] for (k, a0, a1, v) in rec.log], events=ev,
-                         episode_count=int(sim.episode_count))
+                         episode_count=int(sim.episode_count),
+                         logger_calls={str(i): logger_calls[i] for i in range(A)}, progress=progress)
         print(name, len(ev), "events", sum(1 for e in ev if e[0] == "gae"), "trajectories",
               sum(1 for e in ev if e[0] == "gae" and e[2] == 0.0), "terminal")
     with open(os.path.join(OUT, "train_trace.json"), "w") as f:
@@ -743,9 +820,11 @@ if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss", "refresh"]
+    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss", "refresh"]
     if "env" in which:
         gen_env_scenarios()
+    if "envforms" in which:
+        gen_env_callforms()
     if "gae" in which:
         gen_gae()
     if "ff" in which:

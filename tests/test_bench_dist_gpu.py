@@ -12,18 +12,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_gloo():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the environment: the parent starts two rank processes before any
+    GPU call (torch.distributed.run as a child job), relays rank 0's single JSON line and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--envs-per-gpu", "512", "--backend", "gloo", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["backend"] == "gloo"
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 480 * 512 * 2) < 1.0     # both shards counted
+    assert d["roofline"]["launches_timed"] == sum(d["update_adam_steps"])        # post-KL-stop no-op launches are not averaged in
+
+
+def test_bench_strong_scaling_and_failure_exit_code():
+    """--scaling strong splits the 4096 envs over the ranks; a rank count that does not match WORLD_SIZE exits non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--scaling", "strong",
+           "--backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["envs_per_gpu"] == 2048 and d["config"]["envs_total"] == 4096
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
 
 
 def test_data_parallel_equals_single_process(tmp_path):
@@ -45,6 +63,29 @@ def test_data_parallel_equals_single_process(tmp_path):
     assert a["stop"] == b["stop"]
     assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["entropy"] - b["entropy"]) < 1e-5
     assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=2e-5), float((a["params"] - b["params"]).abs().max())
+
+
+def test_data_parallel_kl_stop_in_the_middle_of_the_loop(tmp_path):
+    """The KL early stop (ppo.py:1250-1261) hits mid-loop: both world sizes stop at the same iteration (the five float64
+    statistics are all-reduced in float64, so the decision does not depend on the rank count), and the remaining no-op
+    iterations leave zeros -- not a growing sum -- in the all-reduced gradient bucket and statistics."""
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "_dp_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r1 = subprocess.run([sys.executable, worker, one, "128", "ffstop"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29761", worker, two, "128", "ffstop"], cwd=ROOT, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = torch.load(one), torch.load(two)
+    assert 1 <= a["stop"] < 10, a["stop"]                      # stopped before train_pi_iters
+    assert a["stop"] == b["stop"]
+    assert abs(a["kl"] - b["kl"]) < 1e-6
+    assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=2e-5)
+    for d in (a, b):
+        assert torch.count_nonzero(d["grads_after"]) == 0 and torch.count_nonzero(d["stats_after"]) == 0
 
 
 def test_data_parallel_cnn_equals_single_process(tmp_path):

@@ -193,6 +193,34 @@ def test_dict_api_adapter_matches_oracle():
             assert np.array_equal(o[0].astype(np.float32), np.asarray(ro[0]).astype(np.float32))
 
 
+@pytest.mark.parametrize("A,obst", [(2, 0), (3, 3)])
+def test_adapter_int_and_none_call_forms_match_oracle(A, obst):
+    """RadSearch.step(int) for several agents (same action for all, NO collision rule: the agents stay stacked on one
+    cell) and step(None) mid-episode (rad_search_env.py:616-627, :676-690); the oracle's handling of both forms is
+    pinned to the reference by tests/golden/envforms_*.npz."""
+    from radiation_ppo_amd.envs import RadSearch
+    env = RadSearch(number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True, seed=SEED)
+    ref = RadSearchOracle(PhiloxDraws(SEED, 0), number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True)
+    rng = np.random.default_rng(3)
+    steps = 0
+    for t in range(60):
+        m = t % 6
+        act = int(rng.integers(0, 8)) if m == 1 else (-1 if m == 4 else (None if m == 3 else {i: int(rng.integers(0, 9)) for i in range(A)}))
+        o, r, d, i = env.step(act)
+        ro, rr, rd, ri = ref.step(act)
+        for a in range(A):
+            assert np.array_equal(o[a].astype(np.float32), np.asarray(ro[a]).astype(np.float32)), (t, a)
+            assert r["individual_reward"][a] == rr["individual_reward"][a], (t, a)
+            assert d[a] == rd[a] and i[a] == ri[a], (t, a)
+        assert r["team_reward"] == rr["team_reward"], t
+        steps += 1
+        if ref.done or steps == 20:
+            o, r, d, i = env.reset()
+            ro, rr, rd, ri = ref.reset()
+            assert np.array_equal(o[0].astype(np.float32), np.asarray(ro[0]).astype(np.float32))
+            steps = 0
+
+
 def test_single_env_and_max_agents():
     """Edge sizes: one env (a 1-lane wave) and the maximum agent count (RS_MAX_AGENTS = 8) with collisions galore."""
     _run(N=1, A=1, obst=0, enforce=True, steps=30, seed=11)

@@ -177,6 +177,8 @@ def test_cnn_collector_follows_the_pinned_train_loop():
     buf = col.buf
     obs, act, rew, val, logp, cut, lastv = (x.cpu().numpy() for x in (buf.obs, buf.act, buf.rew, buf.val, buf.logp, buf.cut, buf.last_val))
     ep_ret_sum, ep_len_sum, ep_cnt = 0.0, 0.0, 0
+    ep_rets = {i: [] for i in range(A)}
+    done_cnt, oob_cnt = np.zeros(A), np.zeros(A)
     for n in range(N):
         ref = RadSearchOracle(PhiloxDraws(SEED, n), number_agents=A, obstruction_count=0, enforce_grid_boundaries=True)
         st = {"t": 0, "after_step": False}
@@ -223,8 +225,17 @@ def test_cnn_collector_follows_the_pinned_train_loop():
         ep_ret_sum += sum(e[3] for e in ev if e[0] == "log" and e[1] == 0 and e[2] == "EpRet")
         ep_len_sum += sum(e[3] for e in ev if e[0] == "log" and e[1] == 0 and e[2] == "EpLen")
         ep_cnt += sum(1 for e in ev if e[0] == "ep_len" and e[1] == 0)
+        for i in range(A):                           # what train() stores on logger i (train.py:494-526)
+            ep_rets[i] += [e[3] for e in ev if e[0] == "log" and e[1] == i and e[2] == "EpRet"]
+            done_cnt[i] += sum(e[3] for e in ev if e[0] == "log" and e[1] == i and e[2] == "DoneCount")
+            oob_cnt[i] += sum(e[3] for e in ev if e[0] == "log" and e[1] == i and e[2] == "OutOfBound")
     assert int(stats["EpCount"].item()) == ep_cnt and float(stats["EpLenSum"].item()) == ep_len_sum
-    assert abs(float(stats["EpRetSum"].item()) - ep_ret_sum) < 1e-4
+    assert abs(float(stats["EpRetSum"][0].item()) - ep_ret_sum) < 1e-4
+    for i in range(A):                               # the per-agent logger columns: MeanEpRet StdEpRet MaxEpRet MinEpRet DoneCount OutOfBound
+        r = np.array(ep_rets[i], dtype=np.float64)
+        assert abs(float(stats["EpRetSum"][i]) - r.sum()) < 1e-4 and abs(float(stats["EpRetSqSum"][i]) - (r * r).sum()) < 1e-3
+        assert abs(float(stats["EpRetMax"][i]) - r.max()) < 1e-5 and abs(float(stats["EpRetMin"][i]) - r.min()) < 1e-5
+        assert float(stats["DoneCount"][i]) == done_cnt[i] and float(stats["OutOfBound"][i]) == oob_cnt[i]
 
 
 def test_cnn_update_losses_and_gradients_match_reference(golden_dir):

@@ -19,9 +19,15 @@ def test_action_table(golden_dir):
     assert np.array_equal(table, np.array(ACTION_STEP, dtype=np.float64))
 
 
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+FORM_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "envforms_*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES + FORM_FILES, ids=[os.path.basename(f)[:-4] for f in FILES + FORM_FILES])
 def test_env_transitions_exact(path):
+    """env_*: dict actions (and the single-int form for one agent).  envforms_*: step(int) for SEVERAL agents (same
+    action for all, no collision rule) and step(None) mid-episode (rad_search_env.py:616-627, :676-690)."""
     g = dict(np.load(path).items())
+    form = g.get("form")
     seed, A, enforce = (int(v) for v in g["meta"])
     draws = ReplayDraws([(int(k), a0, a1, v) for (_, k, a0, a1, v) in g["draws"]])
     n_events = len(g["is_reset"])
@@ -38,7 +44,8 @@ def test_env_transitions_exact(path):
                 ret = env.reset()
             else:
                 acts = [int(a) for a in g["actions"][e]]
-                ret = env.step({i: acts[i] for i in range(A)})
+                f = 0 if form is None else int(form[e])
+                ret = env.step({i: acts[i] for i in range(A)}) if f == 0 else env.step(acts[0] if f == 1 else None)
         obs, rew, done, info = ret
         for i in range(A):
             ag = env.agents[i]

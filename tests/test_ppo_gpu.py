@@ -114,6 +114,18 @@ def test_collector_rollout_replays_through_oracle():
     assert 1 <= res.stop_iteration <= 40 and np.isfinite(res.loss_policy)
 
 
+def test_normalize_advantages_matches_reference_buffer(golden_dir):
+    """P3: PPOBuffer.get (ppo.py:445-446) normalises with mpi_statistics_scalar's mean and POPULATION std, no epsilon;
+    the product function on the reference's raw advantages must give the reference's normalised ones (gae.npz)."""
+    from radiation_ppo_amd.ppo import normalize_advantages
+    g = np.load(os.path.join(golden_dir, "gae.npz"))
+    adv = torch.from_numpy(g["adv_raw"].astype(np.float32)).cuda()
+    got = normalize_advantages(adv).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == g["adv_norm"].shape
+    assert np.allclose(got, g["adv_norm"], rtol=2e-6, atol=2e-7), float(np.abs(got - g["adv_norm"]).max())
+    assert abs(float(got.mean())) < 1e-6 and abs(float(got.std()) - 1.0) < 1e-5
+
+
 def test_train_ppo_entry_point_runs():
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.train import train_PPO
@@ -242,6 +254,23 @@ def test_fused_collector_replays_through_oracle(obst):
     hi = torch.where(a < 7, cdf.gather(1, a.unsqueeze(1)).squeeze(1), torch.full_like(cdf[:, 0], 2.0))
     assert (hi - lo > -1e-5).all()
     assert int(stats["EpCount"].item()) >= N * (T // L) - N
+    # episode statistics handed to the logger (MeanEpRet / StdEpRet / MaxEpRet / MinEpRet / EpLen, train.py:494-501, :620):
+    # rebuilt from the buffer -- float32 running return per episode, an episode counts when it ended on a terminal or a
+    # timeout (an epoch cut alone does not; a terminal is the cut whose bootstrap value is exactly 0)
+    rew, cut, lastv = (x[:, :, 0].cpu().numpy() for x in (buf.rew, buf.cut, buf.last_val))
+    rets, lens = [], []
+    for n in range(N):
+        acc, run = np.float32(0.0), 0
+        for t in range(T):
+            acc = np.float32(acc + rew[t, n]); run += 1
+            if cut[t, n]:
+                if t < T - 1 or run == L or lastv[t, n] == 0.0:
+                    rets.append(float(acc)); lens.append(run)
+                acc, run = np.float32(0.0), 0
+    rets = np.array(rets)
+    assert int(stats["EpCount"].item()) == len(rets) and float(stats["EpLenSum"].item()) == float(sum(lens))
+    assert abs(float(stats["EpRetSum"][0]) - rets.sum()) < 1e-3 and abs(float(stats["EpRetSqSum"][0]) - (rets ** 2).sum()) < 1e-2
+    assert abs(float(stats["EpRetMax"][0]) - rets.max()) < 1e-6 and abs(float(stats["EpRetMin"][0]) - rets.min()) < 1e-6
     # second epoch continues (state carried in the collector tensors) and still replays
     col.collect()
     res = col.update()[0]

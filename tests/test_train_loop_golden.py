@@ -94,3 +94,36 @@ def test_rada2c_loss_gradients_and_adam_step_match_reference(golden_dir):
                 assert np.allclose(got[big], want[big], rtol=0, atol=2e-7), (tag, pre + k)
                 assert np.abs(got - want).max() <= 6.1e-4, (tag, pre + k)
     assert bool(d["step_term"]) is False and bool(d["stop_term"]) is True
+
+
+@pytest.mark.parametrize("name", ["a1_individual", "a2_team", "a1_mlp_standardized"])
+def test_epoch_logger_reproduces_the_reference_progress_file(golden_dir, tmp_path, name):
+    """Row T / f4: every store / log_tabular / dump_tabular call the reference's train() made on its loggers
+    (train.py:429, :496-526, :577-627) is replayed on the build's EpochLogger; the progress.txt it writes must equal,
+    byte for byte, the file the reference's own EpochLogger (epoch_logger.py:110-403) wrote in the same run -- header
+    (MeanVVals StdVVals MaxVVals MinVVals ... MeanEpRet StdEpRet MaxEpRet MinEpRet DoneCount EpLen Time) and values;
+    only the wall-clock Time column is exempt."""
+    from radiation_ppo_amd.logger import EpochLogger
+    from radiation_ppo_amd.train import COLUMNS
+    with open(os.path.join(golden_dir, "train_trace.json")) as f:
+        g = json.load(f)[name]
+    for aid, calls in g["logger_calls"].items():
+        lg = EpochLogger(output_dir=str(tmp_path / f"{name}_{aid}"))
+        for c in calls:
+            if c[0] == "store":
+                lg.store(**c[1])
+            elif c[0] == "log_tabular":
+                lg.log_tabular(c[1], c[2], **c[3])
+            else:
+                lg.dump_tabular()
+        lg.output_file.flush()
+        got = open(os.path.join(lg.output_dir, "progress.txt")).read().splitlines()
+        want = g["progress"][aid].splitlines()
+        assert got[0] == want[0]
+        head = want[0].split("\t")
+        assert head == COLUMNS[:len(head)] and COLUMNS[len(head):] == ["EnvStepsPerSec", "PPOItersPerSec"]
+        t_col = head.index("Time")
+        assert len(got) == len(want) == g["epochs"] + 1
+        for a, b in zip(got[1:], want[1:]):
+            a, b = a.split("\t"), b.split("\t")
+            assert a[:t_col] == b[:t_col] and a[t_col + 1:] == b[t_col + 1:], (a, b)
