@@ -18,6 +18,9 @@ SOURCES = ["rs_env.hip", "rs_ppo.hip", "rs_maps.hip", "rs_cnn.hip"]
 # -ffp-contract=off: float64 env arithmetic must round like the reference's Python floats (no FMA fusing)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
           "-Wno-unused-function"]
+# rs_ppo.hip: no SLP packing.  hipcc otherwise pairs the scalar f32 FMAs of the output layer into v_pk_fma_f32 + v_mov shuffles,
+# which costs more issue slots than it saves next to f32 MFMAs (measured: scripts/micro/mfma_valu_coissue.hip)
+EXTRA_CFLAGS = {"rs_ppo.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -38,17 +41,20 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), suffix: str = "") -> str:
+    """defines / suffix: a diagnostic variant next to the product library, e.g. build(defines=["RS_K7_STAMPS"],
+    suffix="_stamps") -> lib/librs_hip_stamps.so (selected with RS_LIB_PATH; see scripts/k7_stamps.py)."""
     deps = _deps()
-    if not force and not _newer(LIB, deps):
-        return LIB
+    lib = LIB.replace(".so", suffix + ".so")
+    if not force and not _newer(lib, deps):
+        return lib
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, src.replace(".hip", suffix + ".o"))
         if force or _newer(obj, deps):
-            cmd = [cc] + CFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [cc] + CFLAGS + EXTRA_CFLAGS.get(src, []) + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print("[radiation_ppo_amd.build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -56,12 +62,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print("[radiation_ppo_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build(force="--force" in sys.argv, defines=["RS_K7_STAMPS"], suffix="_stamps")
+    else:
+        build(force="--force" in sys.argv)

@@ -228,13 +228,32 @@ int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const r
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(rs_ppo_grad2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess)
         return RS_ERR_HIP;
-    hipLaunchKernelGGL(rs_ppo_grad2_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
-    hipLaunchKernelGGL(rs_ppo_grad2_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(512), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
+    int threads = 512;
+#ifdef RS_K7_STAMPS
+    // diagnostic build only: RS_K7_THREADS=256 runs ONE wave per SIMD (half of the groups are skipped: results are wrong, the
+    // per-phase cycle counts are those of a wave that has its SIMD to itself)
+    if (const char* e = getenv("RS_K7_THREADS")) threads = atoi(e) == 256 ? 256 : 512;
+#endif
+    hipLaunchKernelGGL(rs_ppo_grad2_kernel<8>, dim3(RS_GRAD_BLOCKS), dim3(threads), lds_a, s, to_dev(actor), *batch, pa, sa, stop_flag);
+    hipLaunchKernelGGL(rs_ppo_grad2_kernel<1>, dim3(RS_GRAD_BLOCKS), dim3(threads), lds_c, s, to_dev(critic), *batch, pc, sc, stop_flag);
     const int np = rs_net_params(8) + rs_net_params(1);
     hipLaunchKernelGGL(rs_ppo_reduce_kernel, dim3((np + 63) / 64), dim3(1024), 0, s, pa, pc, sa, sc, slabs, grads, stats,
                        batch->alpha, batch->vf_coef, stop_flag);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
+
+#ifdef RS_K7_STAMPS
+// diagnostic build only: read (and optionally clear) the phase-cycle table of rs_ppo_grad2_kernel; out[2][16]
+int rs_debug_k7_stamps(unsigned long long* out, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return RS_ERR_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rs_k7_stamp_table), sizeof(unsigned long long) * 2 * RS_K7_NPH) != hipSuccess) return RS_ERR_HIP;
+    if (clear) {
+        unsigned long long z[2 * RS_K7_NPH] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rs_k7_stamp_table), z, sizeof(z)) != hipSuccess) return RS_ERR_HIP;
+    }
+    return RS_OK;
+}
+#endif
 
 int rs_policy_forward(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* x, int32_t M,
                       float* logits, float* value, rs_stream_t stream) {

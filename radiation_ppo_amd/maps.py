@@ -108,7 +108,7 @@ class ConvTrunk(torch.autograd.Function):
     agent >= 0: the owner's 6-channel actor input; agent < 0: the 4-channel critic input."""
 
     @staticmethod
-    def forward(ctx, maps, cells, pcells, agent, w1, b1, w2, b2):
+    def forward(ctx, maps, cells, pcells, agent, w1, b1, w2, b2, grad_mode=True):
         lib = _lib.load()
         S = maps.shape[0]
         assert maps.dtype == torch.float32 and maps.is_contiguous() and maps[0].numel() == 4 * 729
@@ -119,7 +119,9 @@ class ConvTrunk(torch.autograd.Function):
             A = cells.shape[1]
         w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         assert w1c.shape == (8, 6 if agent >= 0 else 4, 3, 3) and w2c.shape == (16, 8, 3, 3)
-        train = any(ctx.needs_input_grad[4:8])
+        # grad_mode = torch.is_grad_enabled() of the CALLER (inside forward() autograd is always off): the collectors run
+        # under no_grad and must not pay for the activations only backward reads
+        train = bool(grad_mode) and any(ctx.needs_input_grad[4:8])
         a2 = torch.empty(S, 2704, dtype=torch.float32, device=maps.device)
         p1 = torch.empty(S, 169, 8, dtype=torch.float32, device=maps.device) if train else None
         amax = torch.empty(S, 169, 8, dtype=torch.uint8, device=maps.device) if train else None
@@ -155,7 +157,7 @@ class ConvTrunk(torch.autograd.Function):
         g = slab.sum(dim=0)
         n1 = 8 * cin * 9
         return (None, None, None, None, g[:n1].view(8, cin, 3, 3), g[n1:n1 + 8], g[n1 + 8:n1 + 8 + 1152].view(16, 8, 3, 3),
-                g[n1 + 8 + 1152:])
+                g[n1 + 8 + 1152:], None)
 
 
 class CNNActor(nn.Module):
@@ -181,7 +183,7 @@ class CNNActor(nn.Module):
         """Owner `agent`'s logits for samples described by the resident shared maps [S,4,X,Y] + cell indices [S,A]:
         HIP trunk (ConvTrunk) + the three Linear layers."""
         a = self.actor
-        x = ConvTrunk.apply(maps, cells, pcells, agent, a[0].weight, a[0].bias, a[3].weight, a[3].bias)
+        x = ConvTrunk.apply(maps, cells, pcells, agent, a[0].weight, a[0].bias, a[3].weight, a[3].bias, torch.is_grad_enabled())
         for layer in list(a)[6:-1]:
             x = layer(x)
         return x
@@ -208,7 +210,7 @@ class CNNCritic(nn.Module):
     def value_from_maps(self, maps):
         """V for samples given as resident shared maps [S,4,X,Y]: HIP trunk (ConvTrunk) + the Linear layers."""
         c = self.critic
-        x = ConvTrunk.apply(maps, None, None, -1, c[0].weight, c[0].bias, c[3].weight, c[3].bias)
+        x = ConvTrunk.apply(maps, None, None, -1, c[0].weight, c[0].bias, c[3].weight, c[3].bias, torch.is_grad_enabled())
         for layer in list(c)[6:]:
             x = layer(x)
         return x.squeeze(-1)

@@ -122,7 +122,9 @@ def test_normalize_advantages_matches_reference_buffer(golden_dir):
     adv = torch.from_numpy(g["adv_raw"].astype(np.float32)).cuda()
     got = normalize_advantages(adv).cpu().numpy()
     assert got.dtype == np.float32 and got.shape == g["adv_norm"].shape
-    assert np.allclose(got, g["adv_norm"], rtol=2e-6, atol=2e-7), float(np.abs(got - g["adv_norm"]).max())
+    # tolerance: the reference reduces the float32 array in float32 (numpy pairwise sums, mpi_tools.py:83-87), the product in
+    # float64 on the device -- the two statistics differ in the last float32 bits
+    assert np.allclose(got, g["adv_norm"], rtol=1e-5, atol=1e-6), float(np.abs(got - g["adv_norm"]).max())
     assert abs(float(got.mean())) < 1e-6 and abs(float(got.std()) - 1.0) < 1e-5
 
 
