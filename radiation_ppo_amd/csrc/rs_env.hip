@@ -127,29 +127,65 @@ __global__ void __launch_bounds__(64) rs_action_uniform_kernel(RsParams P, float
 // whole time-major buffer.  One column (env x agent trajectory stream) per lane; a reverse scan in
 // time with a restart wherever a trajectory was cut.  Every row access is a coalesced 256-byte row.
 // float64 recurrences y = x + (d * y_next) reproduce scipy.signal.lfilter (ppo.py:85) bit for bit.
-__global__ void __launch_bounds__(256) rs_gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
-                                                     const uint8_t* __restrict__ cut, const float* __restrict__ last_val,
-                                                     float* __restrict__ adv, float* __restrict__ ret, int T, int M,
-                                                     double gamma, double gl) {
+//
+// Parallel in TIME as well, without changing a single operation: the scan state is reset at every cut, so a
+// lane that owns the time chunk [t_lo, t_hi] first finds the nearest cut at or after t_hi (episodes are at
+// most steps_per_episode long), replays the scan from there down to t_hi without storing, and then continues
+// through its own chunk storing adv / ret.  480 steps x 4096 columns become 8 chunks x 4096 lanes = 512 waves
+// with a critical path of <= chunk + episode steps instead of 480.  The rows of eight steps are loaded
+// before they are consumed, so the HBM latency is paid once per eight steps.
+#define RS_GAE_U 8
+__global__ void __launch_bounds__(64) rs_gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
+                                                    const uint8_t* __restrict__ cut, const float* __restrict__ last_val,
+                                                    float* __restrict__ adv, float* __restrict__ ret, int T, int M,
+                                                    double gamma, double gl, int chunk) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    const int t_lo = blockIdx.y * chunk;
+    const int t_hi = min(T, t_lo + chunk) - 1;
+    if (t_lo >= T) return;
+    // nearest cut at or after t_hi (none: the scan starts at T-1 from a zero state, as the serial scan does)
+    int t_start = t_hi;
+    while (t_start < T - 1 && cut[(size_t)t_start * M + m] == 0) ++t_start;
     double a_acc = 0.0, r_acc = 0.0, v_next = 0.0;
-    for (int t = T - 1; t >= 0; --t) {
-        const size_t i = (size_t)t * M + m;
-        const double r = (double)rew[i], v = (double)val[i];
-        if (cut[i]) {
-            const double lv = (double)last_val[i];
-            // rews = [..., last_val], vals = [..., last_val]: the appended element seeds both scans
-            v_next = lv;
-            r_acc = lv;          // discount_cumsum(rews)[-1] = last_val
-            a_acc = 0.0;
+    float r8[RS_GAE_U], v8[RS_GAE_U], l8[RS_GAE_U], rn[RS_GAE_U], vn[RS_GAE_U], ln[RS_GAE_U];
+    uint8_t c8[RS_GAE_U], cn[RS_GAE_U];
+    auto load_block = [&](int tb, float (&r)[RS_GAE_U], float (&v)[RS_GAE_U], float (&l)[RS_GAE_U], uint8_t (&c)[RS_GAE_U]) {
+#pragma unroll
+        for (int u = 0; u < RS_GAE_U; ++u) {
+            const int t = max(tb - u, t_lo);                       // past the chunk's first row: re-read row t_lo (never used)
+            const size_t i = (size_t)t * M + m;
+            r[u] = rew[i]; v[u] = val[i]; c[u] = cut[i]; l[u] = last_val[i];
         }
-        const double delta = r + gamma * v_next - v;
-        a_acc = delta + gl * a_acc;
-        r_acc = r + gamma * r_acc;
-        adv[i] = (float)a_acc;
-        ret[i] = (float)r_acc;
-        v_next = v;
+    };
+    load_block(t_start, r8, v8, l8, c8);
+    for (int tb = t_start; tb >= t_lo; tb -= RS_GAE_U) {
+        load_block(tb - RS_GAE_U, rn, vn, ln, cn);                 // the next eight rows travel while these are consumed
+#pragma unroll
+        for (int u = 0; u < RS_GAE_U; ++u) {
+            const int t = tb - u;
+            if (t >= t_lo) {
+                const double r = (double)r8[u], v = (double)v8[u];
+                if (c8[u]) {
+                    const double lv = (double)l8[u];
+                    // rews = [..., last_val], vals = [..., last_val]: the appended element seeds both scans
+                    v_next = lv;
+                    r_acc = lv;          // discount_cumsum(rews)[-1] = last_val
+                    a_acc = 0.0;
+                }
+                const double delta = r + gamma * v_next - v;
+                a_acc = delta + gl * a_acc;
+                r_acc = r + gamma * r_acc;
+                if (t <= t_hi) {
+                    const size_t i = (size_t)t * M + m;
+                    adv[i] = (float)a_acc;
+                    ret[i] = (float)r_acc;
+                }
+                v_next = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RS_GAE_U; ++u) { r8[u] = rn[u]; v8[u] = vn[u]; l8[u] = ln[u]; c8[u] = cn[u]; }
     }
 }
 
@@ -367,9 +403,16 @@ int rs_gae(const float* rew, const float* val, const uint8_t* cut, const float* 
            int32_t T, int32_t M, double gamma, double lam, rs_stream_t stream) {
     if (!rew || !val || !cut || !last_val || !adv || !ret || T < 1 || M < 1) return RS_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int threads = (M >= 256 * 256) ? 256 : 64;
-    hipLaunchKernelGGL(rs_gae_kernel, dim3((M + threads - 1) / threads), dim3(threads), 0, s, rew, val, cut, last_val, adv, ret, T, M,
-                       gamma, gamma * lam);
+    // time chunks: enough lanes to fill the chip (>= ~512 waves) but chunks no shorter than 32 steps (the replay from the
+    // next cut costs up to one episode per chunk)
+    const int col_waves = (M + 63) / 64;
+    int chunks = (512 + col_waves - 1) / col_waves;
+    chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+    int chunk = (T + chunks - 1) / chunks;
+    if (chunk < 32) chunk = 32;
+    chunks = (T + chunk - 1) / chunk;
+    hipLaunchKernelGGL(rs_gae_kernel, dim3(col_waves, chunks), dim3(64), 0, s, rew, val, cut, last_val, adv, ret, T, M,
+                       gamma, gamma * lam, chunk);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

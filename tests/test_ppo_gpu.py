@@ -49,6 +49,37 @@ def test_gae_kernel_random_cuts_vs_oracle():
                 s = t + 1
 
 
+@pytest.mark.parametrize("T,M,p_cut,end_cut", [(480, 200, 0.01, True), (480, 4096, 0.02, True), (33, 70, 0.0, False),
+                                                  (257, 5000, 0.004, False), (1, 64, 1.0, True)])
+def test_gae_kernel_time_chunks_equal_the_serial_scan(T, M, p_cut, end_cut):
+    """The kernel splits the reverse scan into time chunks (each lane replays from the next cut down to its chunk); every
+    value must equal the float64 serial scan of the whole column (scipy.lfilter's recurrence, ppo.py:62-85), including
+    trajectories that span several chunks, columns with no cut at all (zero start state) and T < one chunk."""
+    from radiation_ppo_amd.envs import gae
+    rng = np.random.default_rng(T * 7 + M)
+    rew = rng.normal(size=(T, M)).astype(np.float32)
+    val = rng.normal(size=(T, M)).astype(np.float32)
+    cut = (rng.random((T, M)) < p_cut).astype(np.uint8)
+    if end_cut:
+        cut[-1] = 1
+    lv = rng.normal(size=(T, M)).astype(np.float32)
+    adv, ret = gae(*(torch.from_numpy(a).cuda() for a in (rew, val, cut, lv)), 0.99, 0.9)
+    adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
+    a_acc = np.zeros(M); r_acc = np.zeros(M); v_next = np.zeros(M)
+    ea, er = np.empty((T, M), np.float32), np.empty((T, M), np.float32)
+    for t in range(T - 1, -1, -1):
+        c = cut[t].astype(bool)
+        lvt = lv[t].astype(np.float64)
+        v_next = np.where(c, lvt, v_next); r_acc = np.where(c, lvt, r_acc); a_acc = np.where(c, 0.0, a_acc)
+        r, v = rew[t].astype(np.float64), val[t].astype(np.float64)
+        delta = r + 0.99 * v_next - v
+        a_acc = delta + (0.99 * 0.9) * a_acc
+        r_acc = r + 0.99 * r_acc
+        ea[t], er[t] = a_acc.astype(np.float32), r_acc.astype(np.float32)
+        v_next = v
+    assert np.array_equal(adv, ea) and np.array_equal(ret, er)
+
+
 def test_ff_actor_critic_matches_reference_outputs(golden_dir):
     from radiation_ppo_amd.ppo import FFActorCritic
     g = dict(np.load(os.path.join(golden_dir, "ff_core.npz")).items())
