@@ -1,0 +1,172 @@
+"""PFGRU location predictor, batched over envs and owners on the device.
+
+Mirrors (paths relative to the reference root):
+  PFGRUCell          <- algos/test_cnn/RADTEAM_core.py:1533-1666 (PFRNNBaseCell :1418-1531): a particle-filter GRU (Ma et al.
+                        2020) with 40 particles of `hidden_size` (24) units, soft resampling (alpha 0.7), tanh activation;
+                        same parameter names (fc_z, fc_r, fc_n, fc_obs, hid_obs.0, hid_obs.2), so `predictor.pt` files
+                        interchange (:1654-1666).  NB the reference's `mlp([h, 24, 2], nn.ReLU)` puts a ReLU behind the LAST
+                        layer too (:1574-1577), so predictions are >= 0; kept.
+  PredictorBank      <- how CNNBase uses it (:1790-1795, select_action :1860-1886): every owner holds its own cell and feeds
+                        the prediction into heat-map channel 0.  In the reference's CNN harness the cell is forward-only with
+                        untrained weights (test_cnn/ppo.py:737-738) and the hidden state returned by select_action is never fed
+                        back (test_cnn/train.py:686-693: `hidden` is only ever assigned by reset_hidden), i.e. each prediction is
+                        PFGRU(observation, h0 of the episode); `carry_hidden=True` gives the evident intent instead.
+                        The reference's input concatenation only type-checks for one agent (:1599-1600); with several agents
+                        every owner feeds its OWN (reading, x, y) row here.
+
+Randomness (documented deviation, like the env's): the reference draws the reparameterisation noise, the resampling indices
+and h0 from torch's global CPU generator.  Here they come from a counter-based hash keyed by (seed, GLOBAL env id, owner,
+episode, step, particle, unit), so a rollout does not depend on how envs are sharded over GPUs.  The cell itself takes the draws
+as arguments: tests inject the reference's recorded draws and compare outputs (tests/golden/pfgru.npz).
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_M64 = (1 << 64) - 1
+
+
+def _s64(v: int) -> int:
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    return torch.bitwise_right_shift(x, s) & ((1 << (64 - s)) - 1)
+
+
+def hash_uniform(key: torch.Tensor) -> torch.Tensor:
+    """int64 keys -> float64 uniforms in [0, 1): the splitmix64 finaliser (Steele et al. 2014) on wrapping int64 arithmetic."""
+    x = key * _s64(0x9E3779B97F4A7C15) + _s64(0xD1B54A32D192ED03)
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    x = x ^ _lsr(x, 31)
+    return _lsr(x, 11).double() * (1.0 / 9007199254740992.0)
+
+
+class PFGRUCell(nn.Module):
+    """Batched PFGRUCell.  h [B, P, H] particles, p [B, P] log weights (B = envs, or owners x envs)."""
+
+    def __init__(self, input_size: int = 3, obs_size: int = 3, activation: str = "tanh", use_resampling: bool = True,
+                 num_particles: int = 40, hidden_size: int = 24, resamp_alpha: float = 0.7):
+        super().__init__()
+        if activation != "tanh":
+            raise NotImplementedError("the reference instantiates the predictor with tanh only (RADTEAM_core.py:1790-1795)")
+        self.num_particles, self.input_size, self.h_dim = num_particles, input_size, hidden_size
+        self.resamp_alpha, self.use_resampling = resamp_alpha, use_resampling
+        self.fc_z = nn.Linear(hidden_size + input_size, hidden_size)
+        self.fc_r = nn.Linear(hidden_size + input_size, hidden_size)
+        self.fc_n = nn.Linear(hidden_size + input_size, hidden_size * 2)
+        self.fc_obs = nn.Linear(hidden_size + input_size, 1)
+        self.hid_obs = nn.Sequential(nn.Linear(hidden_size, 24), nn.ReLU(), nn.Linear(24, 2), nn.ReLU())    # :1574-1584
+
+    def init_hidden(self, batch: int, u: Optional[torch.Tensor] = None, device=None):
+        """init_hidden (:1643-1652): h0 ~ U[0,1) (`u` [B, P, H] when the draws are supplied), p0 = log(1 / P)."""
+        dev = device if device is not None else self.fc_z.weight.device
+        h0 = u.to(torch.float32) if u is not None else torch.rand(batch, self.num_particles, self.h_dim, device=dev)
+        p0 = torch.full((batch, self.num_particles), math.log(1.0 / self.num_particles), dtype=torch.float32, device=dev)
+        return h0, p0
+
+    def forward(self, obs: torch.Tensor, hx: Tuple[torch.Tensor, torch.Tensor], eps: torch.Tensor, resample_u: Optional[torch.Tensor] = None,
+                resample_idx: Optional[torch.Tensor] = None):
+        """One step (:1586-1631).  obs [B, in]; eps [B, P, H] standard normals of the reparameterisation (:1517-1530);
+        resampling either from uniforms `resample_u` [B, P] (inverse CDF of the soft-resampling distribution) or from given
+        particle indices `resample_idx` [B, P] (what torch.multinomial returned in the reference, :1485-1496).
+        Returns loc_pred [B, 2], (h1 [B, P, H], p1 [B, P])."""
+        h0, p0 = hx
+        B, P, H = h0.shape
+        obs_in = obs.unsqueeze(1).expand(B, P, obs.shape[-1])
+        obs_cat = torch.cat((h0, obs_in), dim=2)
+        z = torch.sigmoid(self.fc_z(obs_cat))
+        r = torch.sigmoid(self.fc_r(obs_cat))
+        n_1 = self.fc_n(torch.cat((r * h0, obs_in), dim=2))
+        mu_n, var_n = torch.split(n_1, H, dim=2)
+        n = torch.tanh(mu_n + eps * F.softplus(var_n))
+        h1 = (1 - z) * n + z * h0
+        p1 = F.log_softmax(self.fc_obs(torch.cat((h1, obs_in), dim=2)).squeeze(-1) + p0, dim=1)        # :1633-1641
+        if self.use_resampling:                                                                          # :1466-1515
+            a = self.resamp_alpha
+            if resample_idx is None:
+                resamp_prob = a * torch.exp(p1) + (1 - a) / P
+                cdf = torch.cumsum(resamp_prob.double(), dim=1)
+                cdf = cdf / cdf[:, -1:]
+                resample_idx = torch.searchsorted(cdf, resample_u.double().contiguous(), right=True).clamp_(max=P - 1)
+            h1 = torch.gather(h1, 1, resample_idx.unsqueeze(-1).expand(B, P, H))
+            prob_new = torch.exp(torch.gather(p1, 1, resample_idx))
+            prob_new = prob_new / (a * prob_new + (1 - a) / P)
+            prob_new = torch.log(prob_new)
+            p1 = prob_new - torch.logsumexp(prob_new, dim=1, keepdim=True)
+        mean_hid = torch.sum(torch.exp(p1).unsqueeze(-1) * h1, dim=1)
+        return self.hid_obs(mean_hid), (h1, p1)
+
+
+class PredictorBank:
+    """One PFGRUCell per owner, evaluated for all envs at once; what feeds heat-map channel 0 (`rs_maps_update`'s pred)."""
+
+    def __init__(self, num_envs: int, number_agents: int, hidden_size: int = 24, seed: int = 0, env_id_base: int = 0,
+                 carry_hidden: bool = False, device="cuda:0"):
+        self.N, self.A, self.dev = num_envs, number_agents, torch.device(device)
+        self.cells = [PFGRUCell(hidden_size=hidden_size).to(self.dev) for _ in range(number_agents)]
+        self.carry_hidden = carry_hidden
+        P, H = self.cells[0].num_particles, hidden_size
+        self.P, self.H = P, H
+        env = torch.arange(num_envs, dtype=torch.int64, device=self.dev) + int(env_id_base)
+        own = torch.arange(number_agents, dtype=torch.int64, device=self.dev)
+        # key layout: seed | global env id | owner, then (episode, step, kind) and (particle, unit) are mixed in per call
+        self._base = hash_uniform((env.view(1, -1) * 64 + own.view(-1, 1)) ^ _s64(int(seed) * 0x2545F4914F6CDD1D)).mul(2.0 ** 52).long()   # [A, N]
+        self._pu = (torch.arange(P, dtype=torch.int64, device=self.dev).view(P, 1) * 4096
+                    + torch.arange(H, dtype=torch.int64, device=self.dev).view(1, H))                                                          # [P, H]
+        self.h = torch.zeros(number_agents, num_envs, P, H, dtype=torch.float32, device=self.dev)
+        self.p = torch.full((number_agents, num_envs, P), math.log(1.0 / P), dtype=torch.float32, device=self.dev)
+
+    def parameters(self, a: int):
+        return self.cells[a].parameters()
+
+    def _key(self, episode: torch.Tensor, step: torch.Tensor, kind: int) -> torch.Tensor:
+        ctr = (episode.long().view(1, -1) * 100003 + step.long().view(1, -1)) * 8 + kind                    # [1, N]
+        return (self._base * 1000003) ^ (ctr * _s64(0xA24BAED4963EE407))                                   # [A, N]
+
+    @torch.no_grad()
+    def reset(self, episode: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
+        """reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: fresh h0 ~ U[0,1), p0 = log(1/P)."""
+        k = self._key(episode, torch.zeros_like(episode), 0)
+        u = hash_uniform(k.view(self.A, self.N, 1, 1) * 1048583 + self._pu.view(1, 1, self.P, self.H)).float()
+        if mask is None:
+            self.h.copy_(u); self.p.fill_(math.log(1.0 / self.P))
+        else:
+            m = mask.bool().view(1, self.N, 1, 1)
+            self.h = torch.where(m, u, self.h)
+            self.p = torch.where(m.view(1, self.N, 1), torch.full_like(self.p, math.log(1.0 / self.P)), self.p)
+
+    @torch.no_grad()
+    def predict(self, obs: torch.Tensor, episode: torch.Tensor, step: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """select_action's `self.model(obs_tensor, hidden)` (:1872-1879) for every owner and env: obs [N, A, 11] -> pred [N, A, 2]
+        (scaled coordinates).  `mask` restricts the hidden-state update (carry_hidden) to some envs (bootstrap rounds)."""
+        out = torch.empty(self.N, self.A, 2, dtype=torch.float32, device=self.dev)
+        k_eps, k_res = self._key(episode, step, 1), self._key(episode, step, 2)
+        pu = self._pu.view(1, self.P, self.H)
+        for a, cell in enumerate(self.cells):
+            x = obs[:, a, :3].contiguous()
+            u1 = hash_uniform(k_eps[a].view(self.N, 1, 1) * 1048583 + pu)
+            u2 = hash_uniform(k_eps[a].view(self.N, 1, 1) * 1048583 + pu + 2048)
+            eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()          # Box-Muller
+            ru = hash_uniform(k_res[a].view(self.N, 1) * 1048583 + self._pu[:, 0].view(1, self.P))
+            loc, (h1, p1) = cell(x, (self.h[a], self.p[a]), eps, resample_u=ru)
+            out[:, a] = loc
+            if self.carry_hidden:
+                if mask is None:
+                    self.h[a], self.p[a] = h1, p1
+                else:
+                    m = mask.bool()
+                    self.h[a] = torch.where(m.view(-1, 1, 1), h1, self.h[a])
+                    self.p[a] = torch.where(m.view(-1, 1), p1, self.p[a])
+        return out
+
+    def state_dict(self, a: int):
+        return self.cells[a].state_dict()
+
+    def load_state_dict(self, a: int, sd) -> None:
+        self.cells[a].load_state_dict(sd)

@@ -8,8 +8,9 @@ Mirrors (paths relative to the reference root):
                        critic MSE steps (:1020-1045); sample() draws all indexes below the summed length of the
                        COMPLETE episodes (:754-764); separate Adam + StepLR(100, 0.99) for actor and critic;
                        with a global critic only agent 0 updates it (:858)
-The location-prediction map (PFGRU) is not built: channel 0 stays empty unless the caller
-supplies predictions.
+Heat-map channel 0 (location prediction) is fed by every owner's PFGRU cell (radiation_ppo_amd/pfgru.py, SURVEY section 8 row
+f1) exactly as the reference's CNN harness uses it: forward-only, untrained weights, every prediction made from the episode's
+h0 (algos/test_cnn/train.py:686-693, ppo.py:737-738); `use_predictor=False` leaves the channel empty.
 """
 import os
 from typing import Any, Dict, Optional
@@ -20,6 +21,7 @@ import torch.distributed as dist
 from . import _lib
 from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps
+from .pfgru import PredictorBank
 from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
 
 
@@ -141,6 +143,8 @@ class CNNAgentPPO:
         os.makedirs(path, exist_ok=True)
         torch.save(self.pi.state_dict(), os.path.join(path, "actor.pt"))
         torch.save(self.critic.state_dict(), os.path.join(path, "critic.pt"))
+        if getattr(self, "model", None) is not None:                # PFGRUCell.save_model (:1654-1655)
+            torch.save(self.model.state_dict(), os.path.join(path, "predictor.pt"))
 
     def load(self, path: str) -> None:
         """CNNBase.load (:1945-1953)."""
@@ -148,6 +152,9 @@ class CNNAgentPPO:
             f = os.path.join(path, name)
             assert os.path.isfile(f), "Model does not exist"
             mod.load_state_dict(torch.load(f, map_location=self.device))
+        f = os.path.join(path, "predictor.pt")
+        if getattr(self, "model", None) is not None and os.path.isfile(f):
+            self.model.load_state_dict(torch.load(f, map_location=self.device))
 
     def resume_state(self) -> Dict[str, Any]:
         return dict(actor=self.pi.state_dict(), critic=self.critic.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
@@ -164,7 +171,8 @@ class CNNCollector:
     """Multi-agent RAD-TEAM collector: heat maps (K5) -> CNN actors/critic -> env lock-step -> buffer."""
 
     def __init__(self, env: RadSearchVec, agents: Dict[int, CNNAgentPPO], steps_per_epoch: int, steps_per_episode: int,
-                 global_critic_flag: bool = True):
+                 global_critic_flag: bool = True, use_predictor: bool = True, predictor_hidden_size: int = 24,
+                 carry_hidden: bool = False):
         self.env, self.agents = env, agents
         self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, env.number_agents
         self.team_reward = global_critic_flag
@@ -190,10 +198,19 @@ class CNNCollector:
         self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
         self.complete_len = torch.zeros(self.N, dtype=torch.int64, device=dev)
         self.obs = None
+        # CNNBase.model (RADTEAM_core.py:1790-1795): one PFGRU cell per owner, all envs at once
+        self.predictor: Optional[PredictorBank] = None
+        if use_predictor:
+            self.predictor = PredictorBank(self.N, self.A, hidden_size=predictor_hidden_size, seed=int(env.cfg.seed),
+                                           env_id_base=int(env.cfg.env_id_base), carry_hidden=carry_hidden, device=dev)
+            for a, ag in agents.items():
+                ag.model = self.predictor.cells[a]                  # saved as predictor.pt next to actor.pt / critic.pt
 
     def start(self) -> None:
         obs, *_ = self.env.reset()
         self.obs = obs.clone()
+        if self.predictor is not None:
+            self.predictor.reset(self.env.state("episode")[0])      # ac.reset_hidden() (test_cnn/train.py:686)
 
     def actor_stack_from(self, shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
         """CNNBase.get_map_stack (:1791-1836) for owner a from the stored shared maps: [B,6,X,Y]."""
@@ -210,7 +227,10 @@ class CNNCollector:
     def _round(self, mask: Optional[torch.Tensor] = None):
         """One select_action round of every owner's MapsBuffer (maps updated once, shared by all owners): returns
         the resident shared maps [N,4,X,Y] and the owners' location / prediction cells [N,A]."""
-        self.maps.update(self.obs, mask=mask)
+        pred = None
+        if self.predictor is not None:                              # select_action: location_prediction, _ = self.model(obs, hidden)
+            pred = self.predictor.predict(self.obs, self.env.state("episode")[0], self.env.state("tstep")[0], mask=mask)
+        self.maps.update(self.obs, pred=pred, mask=mask)
         return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
 
     @torch.no_grad()
@@ -266,6 +286,8 @@ class CNNCollector:
             self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
             obs_r, *_ = env.reset(cut)
             self.obs = obs_r.clone()
+            if self.predictor is not None:
+                self.predictor.reset(env.state("episode")[0], mask=cut)         # hidden = ac.reset_hidden() (test_cnn/train.py:770)
             self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
             self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
         buf.finish(self.agents[0].gamma, self.agents[0].lam)

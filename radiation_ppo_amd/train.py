@@ -122,7 +122,9 @@ class train_PPO:
             for ag in self.agents.values():
                 ag.sync_params()
             self.collector = CNNCollector(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode,
-                                          global_critic_flag=self.global_critic_flag)
+                                          global_critic_flag=self.global_critic_flag,
+                                          use_predictor=bool(kw.get("use_predictor", True)),
+                                          predictor_hidden_size=int(kw.get("predictor_hidden_size", 24)))
             return
         self.agents = {i: VecAgentPPO(id=i, actor_critic_architecture=self.actor_critic_architecture,
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}

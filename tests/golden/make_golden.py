@@ -476,6 +476,64 @@ def gen_cnn():
     print("wrote cnn.npz", [k for k in out if k.startswith(("a_", "c_"))])
 
 
+def gen_pfgru():
+    """the PFGRU location predictor exactly as the reference's CNN core instantiates and calls it
+    (algos/test_cnn/RADTEAM_core.py:1790-1795: PFGRUCell(input_size=3, obs_size=3, activation="tanh", hidden_size=24);
+    forward :1586-1631 with soft resampling :1466-1515).  Two traces of 12 steps each: hidden state carried from step to
+    step, and the CNN harness' usage (every step from the episode's h0).  Every random draw the cell makes is recorded: the
+    reparameterisation noise (torch.FloatTensor(shape).normal_(), :1528) by replaying the generator state, the resampling
+    indices by wrapping torch.multinomial (:1485)."""
+    import torch
+    from algos.test_cnn import RADTEAM_core as R
+    torch.manual_seed(29)
+    cell = R.PFGRUCell(input_size=3, obs_size=3, activation="tanh", hidden_size=24)
+    cell.eval()
+    eps_log, idx_log = [], []
+    orig_rep = cell.reparameterize
+
+    def rec_rep(mean, var):
+        st = torch.get_rng_state()
+        out = orig_rep(mean, var)
+        end = torch.get_rng_state()
+        torch.set_rng_state(st)
+        eps_log.append(torch.FloatTensor(var.shape).normal_().clone())       # the same draw the reference just consumed
+        assert torch.equal(torch.get_rng_state(), end)
+        return out
+    cell.reparameterize = rec_rep
+    orig_mn = torch.multinomial
+
+    def rec_mn(*a, **k):
+        r = orig_mn(*a, **k)
+        idx_log.append(r.clone())
+        return r
+    torch.multinomial = rec_mn
+    try:
+        rng = np.random.default_rng(31)
+        T = 12
+        obs = np.stack([rng.poisson(800, T).astype(np.float32) / 100.0, rng.uniform(0.1, 1.0, T).astype(np.float32),
+                        rng.uniform(0.1, 1.0, T).astype(np.float32)], axis=1)
+        out = {"obs": obs}
+        out.update({"sd_" + k: v.numpy() for k, v in cell.state_dict().items()})
+        with torch.no_grad():
+            for tag, carry in (("carry", True), ("fresh", False)):
+                hidden = cell.init_hidden(1)
+                h0 = hidden[0].clone()
+                eps_log.clear(); idx_log.clear()
+                locs, hs, ps = [], [], []
+                for t in range(T):
+                    loc, new_hidden = cell(torch.from_numpy(obs[t:t + 1]), hidden)
+                    if carry:
+                        hidden = new_hidden
+                    locs.append(loc.numpy().copy()); hs.append(new_hidden[0].numpy().copy()); ps.append(new_hidden[1].numpy().reshape(-1).copy())
+                out.update({f"{tag}_h0": h0.numpy(), f"{tag}_eps": torch.stack(eps_log).numpy(),
+                            f"{tag}_idx": torch.stack(idx_log).numpy().reshape(T, -1).astype(np.int64),
+                            f"{tag}_loc": np.stack(locs), f"{tag}_h": np.stack(hs), f"{tag}_p": np.stack(ps)})
+    finally:
+        torch.multinomial = orig_mn
+    np.savez_compressed(os.path.join(OUT, "pfgru.npz"), **out)
+    print("wrote pfgru.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd_")})
+
+
 def gen_round2():
     rng = np.random.default_rng(5)
     sp = np.concatenate([rng.uniform(0, 4000, 200000), rng.integers(0, 400000, 200000) / 100.0,
@@ -820,7 +878,7 @@ if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "train", "loss", "cnnloss", "refresh"]
+    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "pfgru", "train", "loss", "cnnloss", "refresh"]
     if "env" in which:
         gen_env_scenarios()
     if "envforms" in which:
@@ -837,6 +895,8 @@ if __name__ == "__main__":
         gen_maps()
     if "cnn" in which:
         gen_cnn()
+    if "pfgru" in which:
+        gen_pfgru()
     if "train" in which:
         gen_train_trace()
     if "loss" in which:

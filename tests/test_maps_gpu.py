@@ -157,6 +157,53 @@ def test_cnn_collector_replays_through_oracles():
     assert np.isfinite(res[0].loss_policy) and np.isfinite(res[0].loss_critic)
 
 
+def test_predictor_feeds_heat_map_channel_zero():
+    """Row f1 in the collector: every owner's PFGRU prediction (forward-only, from the episode's h0, as the reference's CNN
+    harness runs it) becomes the one-hot of actor channel 0.  A second bank with the same seed and weights, fed the stored
+    observations with the (episode, step) counters rebuilt from the cuts, must reproduce every stored prediction cell
+    int(pred * resolution_accuracy) (MapsBuffer._update_prediction_map, RADTEAM_core.py:747-766); the actor input built by the
+    trunk kernel for the stored cells carries that one-hot."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.pfgru import PredictorBank
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L = 32, 2, 20, 7
+    torch.manual_seed(8)
+    env = RadSearchVec(N, number_agents=A, obstruction_count=1, enforce_grid_boundaries=True, seed=SEED, env_id_base=64)
+    gc = CNNCritic().cuda()
+    agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=torch.optim.Adam(gc.parameters(), lr=1e-3)) for i in range(A)}
+    col = CNNCollector(env, agents, T, L, global_critic_flag=True)
+    assert col.predictor is not None and agents[1].model is col.predictor.cells[1]
+    col.collect()
+    twin = PredictorBank(N, A, seed=SEED, env_id_base=64, device="cuda")
+    for a in range(A):
+        twin.load_state_dict(a, col.predictor.state_dict(a))
+    ra = col.maps.resolution_accuracy
+    episode = torch.ones(N, dtype=torch.int64, device="cuda")       # the env's counter holds the NEXT episode id
+    step = torch.zeros(N, dtype=torch.int64, device="cuda")
+    twin.reset(episode)
+    hits = 0
+    for t in range(T):
+        pred = twin.predict(col.buf.obs[t], episode, step)
+        px, py = (pred[..., 0].double() * ra).long(), (pred[..., 1].double() * ra).long()
+        ok = (px >= 0) & (px < 27) & (py >= 0) & (py < 27)
+        want = px * 27 + py
+        got = col.pcells[t]
+        assert torch.equal(got[ok], want[ok]), t
+        hits += int(ok.sum())
+        cut = col.buf.cut[t, :, 0].bool()
+        step = torch.where(cut, torch.zeros_like(step), step + 1)
+        episode = episode + cut.long()
+        twin.reset(episode, mask=cut)
+    assert hits > N * A * T // 2
+    # channel 0 of the actor input = one-hot of the stored prediction cell
+    stack = col.actor_stack_from(col.shared[5], col.cells[5], col.pcells[5], 1)
+    pc = col.pcells[5][:, 1]
+    for n in range(N):
+        ch0 = stack[n, 0].reshape(-1)
+        assert ch0.sum() == (1.0 if pc[n] >= 0 else 0.0) and (pc[n] < 0 or ch0[pc[n]] == 1.0)
+
+
 def test_cnn_collector_follows_the_pinned_train_loop():
     """The product collector against oracle/train_loop_oracle.train_loop_trace -- the restatement that
     tests/test_train_loop_golden.py pins to the reference's own train() -- env by env: the trace is driven with
