@@ -181,13 +181,9 @@ class EpochLogger(Logger):
         self._emit(key, Stats(n=0, sum=0.0, min=min, max=max, mean=mean, std=std), with_min_and_max, average_only, False)
 
 
-def setup_logger_kwargs(exp_name: str, seed: Optional[int] = None, data_dir: Optional[str] = None, datestamp: bool = False,
-                        env_name: str = "") -> Dict[str, Any]:
-    """rl_tools/run_utils-style helper used by the reference's main.py to build `logger_kwargs`."""
-    ymd_time = time.strftime("%Y-%m-%d_") if datestamp else ""
-    relpath = "".join([ymd_time, exp_name])
+def setup_logger_kwargs(exp_name: str, seed: Optional[int] = None, data_dir: str = "../exp", env_name: Optional[str] = None) -> Dict[str, Any]:
+    """epoch_logger.py:69-107: output_dir = data_dir/(env_name or exp_name)[/<exp_name>_s<seed>]."""
+    relpath = os.path.join(str(data_dir), env_name if env_name else exp_name)
     if seed is not None:
-        sub = "".join([time.strftime("%Y-%m-%d-%H-%M-%S-") if datestamp else "", exp_name, "_s", str(seed)])
-        relpath = os.path.join(relpath, sub)
-    data_dir = data_dir or "."
-    return dict(output_dir=os.path.join(data_dir, relpath), exp_name=exp_name)
+        relpath = os.path.join(relpath, f"{exp_name}_s{seed}")
+    return dict(output_dir=relpath, exp_name=exp_name)

@@ -16,7 +16,7 @@ Mirrors (paths relative to the reference root):
 
 Randomness (documented deviation, like the env's): the reference draws the reparameterisation noise, the resampling indices
 and h0 from torch's global CPU generator.  Here they come from a counter-based hash keyed by (seed, GLOBAL env id, owner,
-episode, step, particle, unit), so a rollout does not depend on how envs are sharded over GPUs.  The cell itself takes the draws
+episode count, prediction count, particle, unit), so a rollout does not depend on how envs are sharded over GPUs.  The cell itself takes the draws
 as arguments: tests inject the reference's recorded draws and compare outputs (tests/golden/pfgru.npz).
 """
 import math
@@ -121,32 +121,35 @@ class PredictorBank:
                     + torch.arange(H, dtype=torch.int64, device=self.dev).view(1, H))                                                          # [P, H]
         self.h = torch.zeros(number_agents, num_envs, P, H, dtype=torch.float32, device=self.dev)
         self.p = torch.full((number_agents, num_envs, P), math.log(1.0 / P), dtype=torch.float32, device=self.dev)
+        # draw counters per env: episodes begun, predictions made in the current episode
+        self.episode = torch.zeros(num_envs, dtype=torch.int64, device=self.dev)
+        self.calls = torch.zeros(num_envs, dtype=torch.int64, device=self.dev)
 
     def parameters(self, a: int):
         return self.cells[a].parameters()
 
-    def _key(self, episode: torch.Tensor, step: torch.Tensor, kind: int) -> torch.Tensor:
-        ctr = (episode.long().view(1, -1) * 100003 + step.long().view(1, -1)) * 8 + kind                    # [1, N]
+    def _key(self, kind: int) -> torch.Tensor:
+        ctr = (self.episode.view(1, -1) * 100003 + self.calls.view(1, -1)) * 8 + kind                       # [1, N]
         return (self._base * 1000003) ^ (ctr * _s64(0xA24BAED4963EE407))                                   # [A, N]
 
     @torch.no_grad()
-    def reset(self, episode: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
-        """reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: fresh h0 ~ U[0,1), p0 = log(1/P)."""
-        k = self._key(episode, torch.zeros_like(episode), 0)
+    def reset(self, mask: Optional[torch.Tensor] = None) -> None:
+        """reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: a new episode, fresh h0 ~ U[0,1), p0 = log(1/P)."""
+        m1 = torch.ones(self.N, dtype=torch.bool, device=self.dev) if mask is None else mask.bool()
+        self.episode = self.episode + m1.long()
+        self.calls = torch.where(m1, torch.zeros_like(self.calls), self.calls)
+        k = self._key(0)
         u = hash_uniform(k.view(self.A, self.N, 1, 1) * 1048583 + self._pu.view(1, 1, self.P, self.H)).float()
-        if mask is None:
-            self.h.copy_(u); self.p.fill_(math.log(1.0 / self.P))
-        else:
-            m = mask.bool().view(1, self.N, 1, 1)
-            self.h = torch.where(m, u, self.h)
-            self.p = torch.where(m.view(1, self.N, 1), torch.full_like(self.p, math.log(1.0 / self.P)), self.p)
+        m = m1.view(1, self.N, 1, 1)
+        self.h = torch.where(m, u, self.h)
+        self.p = torch.where(m.view(1, self.N, 1), torch.full_like(self.p, math.log(1.0 / self.P)), self.p)
 
     @torch.no_grad()
-    def predict(self, obs: torch.Tensor, episode: torch.Tensor, step: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def predict(self, obs: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """select_action's `self.model(obs_tensor, hidden)` (:1872-1879) for every owner and env: obs [N, A, 11] -> pred [N, A, 2]
-        (scaled coordinates).  `mask` restricts the hidden-state update (carry_hidden) to some envs (bootstrap rounds)."""
+        (scaled coordinates).  `mask`: the envs this round counts for (bootstrap rounds); the others' rows are to be discarded."""
         out = torch.empty(self.N, self.A, 2, dtype=torch.float32, device=self.dev)
-        k_eps, k_res = self._key(episode, step, 1), self._key(episode, step, 2)
+        k_eps, k_res = self._key(1), self._key(2)
         pu = self._pu.view(1, self.P, self.H)
         for a, cell in enumerate(self.cells):
             x = obs[:, a, :3].contiguous()
@@ -163,6 +166,7 @@ class PredictorBank:
                     m = mask.bool()
                     self.h[a] = torch.where(m.view(-1, 1, 1), h1, self.h[a])
                     self.p[a] = torch.where(m.view(-1, 1), p1, self.p[a])
+        self.calls = self.calls + (1 if mask is None else mask.long())
         return out
 
     def state_dict(self, a: int):

@@ -210,7 +210,7 @@ class CNNCollector:
         obs, *_ = self.env.reset()
         self.obs = obs.clone()
         if self.predictor is not None:
-            self.predictor.reset(self.env.state("episode")[0])      # ac.reset_hidden() (test_cnn/train.py:686)
+            self.predictor.reset()                                  # ac.reset_hidden() (test_cnn/train.py:686)
 
     def actor_stack_from(self, shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
         """CNNBase.get_map_stack (:1791-1836) for owner a from the stored shared maps: [B,6,X,Y]."""
@@ -229,7 +229,7 @@ class CNNCollector:
         the resident shared maps [N,4,X,Y] and the owners' location / prediction cells [N,A]."""
         pred = None
         if self.predictor is not None:                              # select_action: location_prediction, _ = self.model(obs, hidden)
-            pred = self.predictor.predict(self.obs, self.env.state("episode")[0], self.env.state("tstep")[0], mask=mask)
+            pred = self.predictor.predict(self.obs, mask=mask)
         self.maps.update(self.obs, pred=pred, mask=mask)
         return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
 
@@ -287,7 +287,7 @@ class CNNCollector:
             obs_r, *_ = env.reset(cut)
             self.obs = obs_r.clone()
             if self.predictor is not None:
-                self.predictor.reset(env.state("episode")[0], mask=cut)         # hidden = ac.reset_hidden() (test_cnn/train.py:770)
+                self.predictor.reset(mask=cut)                              # hidden = ac.reset_hidden() (test_cnn/train.py:770)
             self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
             self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
         buf.finish(self.agents[0].gamma, self.agents[0].lam)

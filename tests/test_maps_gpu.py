@@ -179,22 +179,21 @@ def test_predictor_feeds_heat_map_channel_zero():
     for a in range(A):
         twin.load_state_dict(a, col.predictor.state_dict(a))
     ra = col.maps.resolution_accuracy
-    episode = torch.ones(N, dtype=torch.int64, device="cuda")       # the env's counter holds the NEXT episode id
-    step = torch.zeros(N, dtype=torch.int64, device="cuda")
-    twin.reset(episode)
+    twin.reset()
     hits = 0
     for t in range(T):
-        pred = twin.predict(col.buf.obs[t], episode, step)
+        pred = twin.predict(col.buf.obs[t])
         px, py = (pred[..., 0].double() * ra).long(), (pred[..., 1].double() * ra).long()
         ok = (px >= 0) & (px < 27) & (py >= 0) & (py < 27)
         want = px * 27 + py
         got = col.pcells[t]
         assert torch.equal(got[ok], want[ok]), t
         hits += int(ok.sum())
+        # the collector's bootstrap round (timeouts / epoch end) makes one more prediction for those envs, then they restart
         cut = col.buf.cut[t, :, 0].bool()
-        step = torch.where(cut, torch.zeros_like(step), step + 1)
-        episode = episode + cut.long()
-        twin.reset(episode, mask=cut)
+        boot = cut & (col.buf.last_val[t, :, 0] != 0)
+        twin.calls += boot.long()
+        twin.reset(mask=cut)
     assert hits > N * A * T // 2
     # channel 0 of the actor input = one-hot of the stored prediction cell
     stack = col.actor_stack_from(col.shared[5], col.cells[5], col.pcells[5], 1)

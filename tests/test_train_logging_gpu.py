@@ -95,7 +95,10 @@ def test_cnn_checkpoint_files_match_reference_names(tmp_path, golden_dir):
             assert torch.equal(a, b)
         s1, s2 = sim.agents[i].pi_optimizer.state_dict()["state"], sim2.agents[i].pi_optimizer.state_dict()["state"]
         assert all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1)
-    # a CNN checkpoint written by the reference's naming loads through CNNAgentPPO.load
+    # a CNN checkpoint written by the reference's naming loads through CNNAgentPPO.load (train() saves BEFORE an epoch's update,
+    # train.py:552-569, so the files are rewritten from the final weights first)
+    sim.save()
+    assert (tmp_path / "1_agent" / "predictor.pt").exists()          # PFGRUCell.save_model (RADTEAM_core.py:1654-1655)
     sim2.agents[0].load(str(tmp_path / "1_agent"))
     for a, b in zip(sim2.agents[0].pi.parameters(), sim.agents[1].pi.parameters()):
         assert torch.equal(a, b)
