@@ -9,8 +9,11 @@ with its own Philox stream -- and the same per-environment records come out (`Mo
 
 Saved sets use the reference's layout `env_dict["env_<i>"] = (src_coords, det_coords, intensity, bkg[, obstacles])`
 (algos/test_environment/eval/test_env_gen.py:13-24).  `sample_test_environments` draws such a set from the
-environment's own spawn rules (the reference's pickled sets are not read: they are untrusted binary files).
+environment's own spawn rules; the reference's own pickled sets are read by radiation_ppo_amd.testsets WITHOUT unpickling.
+`run_test_environments_cnn` is the same runner for RAD-TEAM (CNN) policies, `summarize` the result statistics
+(evaluate.py:645-880), `evaluate_PPO` the driver with the reference's eval_kwargs (:581-643).
 """
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, List
 
@@ -139,6 +142,86 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
     flags = vec.error_flags()
     if flags:
         raise RuntimeError(f"RadSearch env error flags 0x{flags:x}")
+    out = _collect_results(keys, E, R, ep_len, ep_ret, success, inten, bkg)
+    summary = summarize(out)
+    if return_actions:
+        return out, summary, torch.stack(log).cpu().numpy()
+    return out, summary
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RAD-TEAM (CNN) policies, result summaries and the evaluate_PPO driver
+@torch.no_grad()
+def run_test_environments_cnn(agents: Dict[int, Any], env_sets: Dict[str, tuple], montecarlo_runs: int = 100,
+                              steps_per_episode: int = 120, team_mode: str = "individual", obstruction_count: int = 0,
+                              enforce_grid_boundaries: bool = True, seed: int = 0, device: str = "cuda:0",
+                              use_predictor: bool = True, return_actions: bool = False):
+    """EpisodeRunner.run (evaluate.py:333-476) for the 'cnn' architecture: every (saved environment, Monte-Carlo run) pair is one
+    env; per step the heat maps are updated from all agents' observations (with every owner's PFGRU prediction in channel 0),
+    each CNN actor samples its action (`ac.step(observations, hiddens)`, :383), the env steps, and an episode ends when any
+    agent's terminal flag is raised or at `steps_per_episode`; the maps restart with each episode (`agent.reset()`, :471-473).
+    team_mode "individual": agent 0's own reward is accumulated (`episode_return[0]`, :400-447), otherwise the team reward.
+    agents: {id: CNNAgentPPO}.  Returns (List[MonteCarloResults], summary)."""
+    from .maps import HeatMaps
+    from .pfgru import PredictorBank
+    A = len(agents)
+    E, R, L = len(env_sets), montecarlo_runs, steps_per_episode
+    N = E * R
+    dev = torch.device(device)
+    with_obs = obstruction_count != 0
+    vec = RadSearchVec(N, number_agents=A, obstruction_count=obstruction_count, enforce_grid_boundaries=enforce_grid_boundaries,
+                       seed=seed, device=device)
+    keys, src, det, inten, bkg, nob, rects = _pack(env_sets, R, with_obs, dev)
+    vec.reset()
+    obs = vec.refresh(src, det, inten, bkg, nob, rects)[0].clone()
+    maps = HeatMaps(vec, L, enforce_boundaries=bool(enforce_grid_boundaries))
+    if maps.map_dimensions != (27, 27):
+        raise NotImplementedError("the CNN trunk kernels are built for 27 x 27 heat maps (enforce_grid_boundaries=True)")
+    bank = None
+    if use_predictor:
+        bank = PredictorBank(N, A, seed=seed, device=dev)
+        for a, ag in agents.items():
+            if getattr(ag, "model", None) is not None:                # the agent's own (saved) predictor weights
+                bank.load_state_dict(a, ag.model.state_dict())
+        bank.reset()
+    alive = torch.ones(N, dtype=torch.bool, device=dev)
+    ep_len = torch.zeros(N, dtype=torch.int32, device=dev)
+    ep_ret = torch.zeros(N, dtype=torch.float32, device=dev)
+    success = torch.zeros(N, dtype=torch.bool, device=dev)
+    u = torch.empty(N, A, dtype=torch.float32, device=dev)
+    act8 = torch.empty(N, A, dtype=torch.int8, device=dev)
+    log = []
+    for _ in range(L):
+        pred = bank.predict(obs) if bank is not None else None
+        maps.update(obs, pred=pred)
+        shared, cells, pcells = maps.shared_maps(), maps.field("cell").long(), maps.field("pred_cell").long()
+        vec.action_uniforms(u)
+        for a, ag in agents.items():
+            act, _ = ag.act((shared, cells, pcells, a), u[:, a])
+            act8[:, a] = torch.where(alive, act, torch.full_like(act, 8)).to(torch.int8)       # finished episodes idle in place
+        if return_actions:
+            log.append(act8.clone())
+        obs_n, rew, team, done, _ = vec.step(act8)
+        r = rew[:, 0] if team_mode == "individual" else team
+        ep_ret += torch.where(alive, r, torch.zeros_like(r))
+        ep_len += alive.int()
+        found = done.bool().any(dim=1) & alive
+        success |= found
+        alive &= ~found
+        obs = obs_n.clone()
+        if not bool(alive.any()):
+            break
+    flags = vec.error_flags() & ~_lib.ENVERR_IDLE_STALL        # finished episodes idle on purpose; stacked agents may "stall"
+    if flags:
+        raise RuntimeError(f"RadSearch env error flags 0x{flags:x}")
+    out = _collect_results(keys, E, R, ep_len, ep_ret, success, inten, bkg)
+    summary = summarize(out)
+    if return_actions:
+        return out, summary, torch.stack(log).cpu().numpy()
+    return out, summary
+
+
+def _collect_results(keys, E, R, ep_len, ep_ret, success, inten, bkg) -> List[MonteCarloResults]:
     ep_len_c, ep_ret_c, suc = ep_len.cpu().numpy(), ep_ret.cpu().numpy(), success.cpu().numpy()
     i_c, b_c = inten.cpu().numpy(), bkg.cpu().numpy()
     out: List[MonteCarloResults] = []
@@ -147,21 +230,115 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
         for r in range(R):
             n = e * R + r
             bucket = res.successful if suc[n] else res.unsuccessful
-            if r < 1:                                             # :425-431
+            if r < 1:                                             # evaluate.py:425-431
                 bucket.intensity.append(int(i_c[n])); bucket.background_intensity.append(int(b_c[n]))
             res.total_episode_length.append(int(ep_len_c[n]))
             res.success_counter += int(suc[n])
             bucket.episode_length.append(int(ep_len_c[n])); bucket.episode_return.append(float(ep_ret_c[n]))
         res.completed_runs = R
         out.append(res)
-    done_len = [l for r in out for l in r.successful.episode_length]
-    done_ret = [l for r in out for l in r.successful.episode_return]
-    nd_ret = [l for r in out for l in r.unsuccessful.episode_return]
-    summary = {"episodes": E, "montecarlo_runs": R, "completed_runs": N,
-               "success_rate": float(suc.mean()), "success_count_median": float(np.median([r.success_counter for r in out])),
-               "successful_episode_length_median": float(median(done_len)), "successful_episode_return_median": float(median(done_ret)),
-               "unsuccessful_episode_return_median": float(median(nd_ret)),
-               "total_episode_length_median": float(np.median(ep_len_c))}
-    if return_actions:
-        return out, summary, torch.stack(log).cpu().numpy()
-    return out, summary
+    return out
+
+
+def variance(data) -> float:             # evaluate.py:83-85
+    return float(np.var(data)) if len(data) > 0 else float("nan")
+
+
+def weighted_quantiles(values, weights, qs):
+    """Quantiles of a weighted sample (what the reference asks statsmodels' DescrStatsW for, evaluate.py:742-760): the smallest value
+    whose cumulative weight reaches q of the total."""
+    v, w = np.asarray(values, dtype=np.float64), np.asarray(weights, dtype=np.float64)
+    keep = np.isfinite(v) & (w > 0)
+    v, w = v[keep], w[keep]
+    if v.size == 0:
+        return [float("nan")] * len(qs)
+    order = np.argsort(v, kind="stable")
+    v, cw = v[order], np.cumsum(w[order])
+    return [float(v[min(np.searchsorted(cw, q * cw[-1], side="left"), v.size - 1)]) for q in qs]
+
+
+def summarize(results: List[MonteCarloResults]) -> Dict[str, Any]:
+    """evaluate_PPO.parse_results / calc_stats (evaluate.py:645-880).  The reference's parse_results is unfinished -- every
+    median it stores reads `scenario.successful.background_intensity` and it ends in an undefined `keys` -- so this follows the
+    evident intent spelled out in calc_stats' comments: per scenario (saved environment) the success count and the median /
+    variance of the returns, lengths, intensities and backgrounds of its successful and unsuccessful runs, the distribution of
+    successful episode lengths (unique values ordered by count), and over all scenarios the run-weighted median and
+    2.5 / 25 / 75 / 97.5 percentiles of the success count and of the successful episode length."""
+    per = []
+    for sc in results:
+        uni, cnt = np.unique(sc.successful.episode_length, return_counts=True) if sc.successful.episode_length else (np.array([]), np.array([]))
+        order = np.argsort(cnt, kind="stable")
+        per.append({"id": sc.id, "runs": sc.completed_runs, "success_count": sc.success_counter,
+                    "successful": {k: (float(median(getattr(sc.successful, k))), variance(getattr(sc.successful, k)))
+                                   for k in ("episode_return", "episode_length", "intensity", "background_intensity")},
+                    "unsuccessful": {k: (float(median(getattr(sc.unsuccessful, k))), variance(getattr(sc.unsuccessful, k)))
+                                     for k in ("episode_return", "episode_length", "intensity", "background_intensity")},
+                    "success_length_distribution": {"unique": [int(x) for x in uni[order]], "counts": [int(x) for x in cnt[order]]}})
+    runs = np.array([p["runs"] for p in per], dtype=np.float64)
+    succ = np.array([p["success_count"] for p in per], dtype=np.float64)
+    med_len = np.array([p["successful"]["episode_length"][0] for p in per])
+    qs = [0.025, 0.25, 0.5, 0.75, 0.975]
+    done_len = [l for r in results for l in r.successful.episode_length]
+    done_ret = [l for r in results for l in r.successful.episode_return]
+    nd_ret = [l for r in results for l in r.unsuccessful.episode_return]
+    tot_len = [l for r in results for l in r.total_episode_length]
+    return {"episodes": len(results), "montecarlo_runs": int(runs[0]) if len(runs) else 0, "completed_runs": int(runs.sum()),
+            "success_rate": float(succ.sum() / max(runs.sum(), 1.0)), "success_count_median": float(np.median(succ)) if len(succ) else float("nan"),
+            "success_count_weighted_quantiles": dict(zip(map(str, qs), weighted_quantiles(succ, runs, qs))),
+            "successful_episode_length_weighted_quantiles": dict(zip(map(str, qs), weighted_quantiles(med_len, succ, qs))),
+            "successful_episode_length_median": float(median(done_len)), "successful_episode_return_median": float(median(done_ret)),
+            "unsuccessful_episode_return_median": float(median(nd_ret)), "total_episode_length_median": float(median(tot_len)),
+            "scenarios": per}
+
+
+@dataclass
+class evaluate_PPO:
+    """evaluate_PPO (evaluate.py:581-643): `eval_kwargs` as the reference builds them in main.py -- test_env_path (directory of the
+    saved sets), obstruction_count (0..7, not -1), snr ('none' | 'low' | 'med' | 'high'), episodes, montecarlo_runs, model_path
+    (directory holding `<id>_agent*/actor.pt, critic.pt[, predictor.pt]` or `<id>_agent*/pyt_save/model.pt`),
+    actor_critic_architecture ('cnn' | 'ff' / 'mlp'), number_of_agents, steps_per_episode, enforce_boundaries, team_mode, seed.
+    The set is read with the safe reader (radiation_ppo_amd.testsets); all episodes x runs advance in lock-step on the device."""
+    eval_kwargs: Dict[str, Any]
+
+    def __post_init__(self) -> None:
+        kw = self.eval_kwargs
+        if kw["obstruction_count"] == -1:
+            raise ValueError("Random sample of obstruction counts indicated. Please indicate a specific count between 1 and 7")
+        self.test_env_dir = kw["test_env_path"]
+        self.test_env_path = os.path.join(self.test_env_dir, f"test_env_dict_obs{kw['obstruction_count']}_{kw.get('snr', 'high')}_v4")
+
+    def evaluate(self):
+        from .testsets import load_test_environments
+        kw = self.eval_kwargs
+        sets = load_test_environments(self.test_env_path)
+        keys = sorted(sets, key=lambda k: int(k.split("_")[1]))[:int(kw.get("episodes", 100))]
+        sets = {k: sets[k] for k in keys}
+        A, arch = int(kw.get("number_of_agents", 1)), kw.get("actor_critic_architecture", "cnn")
+        dev = kw.get("device", "cuda:0")
+        common = dict(montecarlo_runs=int(kw.get("montecarlo_runs", 100)), steps_per_episode=int(kw.get("steps_per_episode", 120)),
+                      obstruction_count=int(kw["obstruction_count"]), enforce_grid_boundaries=bool(kw.get("enforce_boundaries", True)),
+                      seed=int(kw.get("seed", 0) or 0), device=dev)
+
+        def agent_dir(i):
+            cands = sorted(d for d in os.listdir(kw["model_path"]) if d.startswith(f"{i}_agent"))
+            if not cands:
+                raise FileNotFoundError(f"no {i}_agent* directory under {kw['model_path']}")
+            return os.path.join(kw["model_path"], cands[0])
+        if arch == "cnn":
+            from .maps import CNNCritic
+            from .pfgru import PFGRUCell
+            from .ppo_cnn import CNNAgentPPO
+            agents = {}
+            for i in range(A):
+                ag = CNNAgentPPO(id=i, device=dev)
+                ag.model = PFGRUCell().to(dev)
+                ag.load(agent_dir(i))                                   # CNNBase.load (RADTEAM_core.py:1945-1953)
+                agents[i] = ag
+            self.results, self.summary = run_test_environments_cnn(agents, sets, team_mode=kw.get("team_mode", "individual"), **common)
+        else:
+            ag = VecAgentPPO(id=0, device=dev)
+            d = agent_dir(0)
+            f = os.path.join(d, "pyt_save", "model.pt")
+            ag.load(f if os.path.exists(f) else os.path.join(d, "model.pt"))
+            self.results, self.summary = run_test_environments(ag, sets, **common)
+        return self.results, self.summary

@@ -1,6 +1,8 @@
 """radiation_ppo_amd.evaluate.run_test_environments (the batched EpisodeRunner.run, algos/multiagent/evaluate.py:333-476):
 every (saved environment, Monte-Carlo run) episode is replayed through the oracle -- refresh_environment, then the logged
 actions -- and must end at the same step with the same success flag and return; the per-environment records add up."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,3 +55,65 @@ def test_monte_carlo_evaluation_matches_oracle_replay(obst):
             assert any(abs(v - float(ret)) < 1e-4 for v in bucket.episode_return), (e, r, float(ret), bucket.episode_return)
     assert sum(r.success_counter for r in results) == n_success
     assert abs(summary["success_rate"] - n_success / (E * R)) < 1e-9
+
+
+@pytest.mark.parametrize("team_mode", ["individual", "team"])
+def test_cnn_monte_carlo_evaluation_matches_oracle_replay(team_mode):
+    """run_test_environments_cnn: RAD-TEAM policies (2 agents, CNN actors fed by the heat maps + PFGRU channel) evaluated on saved
+    environments with obstacles; each (environment, run) episode replayed through the oracle with the logged joint actions ends at
+    the same step with the same success flag and the same accumulated return (agent 0's own reward, or the team reward)."""
+    from radiation_ppo_amd.evaluate import run_test_environments_cnn, sample_test_environments, summarize
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO
+    torch.manual_seed(4)
+    E, R, L, A, seed, obst = 4, 3, 30, 2, 321, 2
+    sets = sample_test_environments(E, obstruction_count=obst, seed=55)
+    agents = {i: CNNAgentPPO(id=i) for i in range(A)}
+    results, summary, actions = run_test_environments_cnn(agents, sets, montecarlo_runs=R, steps_per_episode=L, team_mode=team_mode,
+                                                          obstruction_count=obst, seed=seed, return_actions=True)
+    assert len(results) == E and summary["completed_runs"] == E * R and len(summary["scenarios"]) == E
+    for e, res in enumerate(results):
+        s = sets[f"env_{e}"]
+        rects = [(int(o[0][:, 0].min()), int(o[0][:, 1].min()), int(o[0][:, 0].max()), int(o[0][:, 1].max())) for o in s[4]]
+        for r in range(R):
+            n = e * R + r
+            ref = RadSearchOracle(PhiloxDraws(seed, n), number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True)
+            ref.refresh_environment(s[0], s[1], s[2], s[3], rects)
+            ret, steps, found = np.float32(0.0), 0, False
+            for t in range(actions.shape[0]):
+                o, rew, done, _ = ref.step({i: int(actions[t, n, i]) for i in range(A)})
+                rr = rew["individual_reward"][0] if team_mode == "individual" else rew["team_reward"]
+                ret = np.float32(ret + np.float32(rr))
+                steps += 1
+                if any(done.values()):
+                    found = True
+                    break
+            assert res.total_episode_length[r] == steps, (e, r)
+            bucket = res.successful if found else res.unsuccessful
+            assert any(abs(v - float(ret)) < 1e-4 for v in bucket.episode_return), (e, r, float(ret), bucket.episode_return)
+    again = summarize(results)
+    assert again["success_rate"] == summary["success_rate"]
+    q = summary["success_count_weighted_quantiles"]
+    assert q["0.025"] <= q["0.5"] <= q["0.975"]
+
+
+def test_evaluate_ppo_driver_reads_a_saved_set_and_saved_models(tmp_path):
+    """evaluate_PPO (evaluate.py:581-643) end to end: a set in the reference's joblib layout on disk (read by the safe reader), models
+    saved by train_PPO under `<id>_agent`, the reference's eval_kwargs."""
+    joblib = pytest.importorskip("joblib")
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.evaluate import evaluate_PPO, sample_test_environments
+    from radiation_ppo_amd.train import train_PPO
+    sets = sample_test_environments(5, obstruction_count=1, seed=3)
+    os.makedirs(tmp_path / "sets")
+    joblib.dump(sets, str(tmp_path / "sets" / "test_env_dict_obs1_low_v4"))
+    env = RadSearchVec(8, number_agents=2, obstruction_count=1, enforce_grid_boundaries=True, seed=2)
+    sim = train_PPO(env=env, logger_kwargs=dict(output_dir=str(tmp_path / "models")), ppo_kwargs=dict(train_pi_iters=1, train_v_iters=1),
+                    seed=2, number_of_agents=2, steps_per_epoch=12, steps_per_episode=6, total_epochs=1)
+    sim.train()
+    ev = evaluate_PPO(dict(test_env_path=str(tmp_path / "sets"), obstruction_count=1, snr="low", episodes=4, montecarlo_runs=3,
+                           model_path=str(tmp_path / "models"), actor_critic_architecture="cnn", number_of_agents=2,
+                           steps_per_episode=10, enforce_boundaries=True, team_mode="team", seed=1))
+    results, summary = ev.evaluate()
+    assert len(results) == 4 and summary["completed_runs"] == 12 and 0.0 <= summary["success_rate"] <= 1.0
+    with pytest.raises(ValueError):
+        evaluate_PPO(dict(test_env_path="x", obstruction_count=-1))
