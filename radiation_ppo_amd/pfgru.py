@@ -144,30 +144,63 @@ class PredictorBank:
         self.h = torch.where(m, u, self.h)
         self.p = torch.where(m.view(1, self.N, 1), torch.full_like(self.p, math.log(1.0 / self.P)), self.p)
 
+    def _stacked(self):
+        """The owners' weights stacked along a leading owner axis ([A, in, out] for bmm); rebuilt when a cell's parameters change
+        (load_state_dict / an optimiser step bump the tensors' version counters)."""
+        ver = tuple(p._version for c in self.cells for p in c.parameters())
+        if getattr(self, "_stack_ver", None) != ver:
+            g = lambda f: torch.stack([f(c) for c in self.cells])
+            self._W = dict(
+                zr=g(lambda c: torch.cat([c.fc_z.weight, c.fc_r.weight], 0).t().contiguous()),     # [A, H+3, 2H]
+                zr_b=g(lambda c: torch.cat([c.fc_z.bias, c.fc_r.bias], 0)).unsqueeze(1),            # [A, 1, 2H]
+                n=g(lambda c: c.fc_n.weight.t().contiguous()), n_b=g(lambda c: c.fc_n.bias).unsqueeze(1),
+                o=g(lambda c: c.fc_obs.weight.t().contiguous()), o_b=g(lambda c: c.fc_obs.bias).unsqueeze(1),
+                h0=g(lambda c: c.hid_obs[0].weight.t().contiguous()), h0_b=g(lambda c: c.hid_obs[0].bias).unsqueeze(1),
+                h2=g(lambda c: c.hid_obs[2].weight.t().contiguous()), h2_b=g(lambda c: c.hid_obs[2].bias).unsqueeze(1))
+            self._stack_ver = ver
+        return self._W
+
     @torch.no_grad()
     def predict(self, obs: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """select_action's `self.model(obs_tensor, hidden)` (:1872-1879) for every owner and env: obs [N, A, 11] -> pred [N, A, 2]
-        (scaled coordinates).  `mask`: the envs this round counts for (bootstrap rounds); the others' rows are to be discarded."""
-        out = torch.empty(self.N, self.A, 2, dtype=torch.float32, device=self.dev)
-        k_eps, k_res = self._key(1), self._key(2)
-        pu = self._pu.view(1, self.P, self.H)
-        for a, cell in enumerate(self.cells):
-            x = obs[:, a, :3].contiguous()
-            u1 = hash_uniform(k_eps[a].view(self.N, 1, 1) * 1048583 + pu)
-            u2 = hash_uniform(k_eps[a].view(self.N, 1, 1) * 1048583 + pu + 2048)
-            eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()          # Box-Muller
-            ru = hash_uniform(k_res[a].view(self.N, 1) * 1048583 + self._pu[:, 0].view(1, self.P))
-            loc, (h1, p1) = cell(x, (self.h[a], self.p[a]), eps, resample_u=ru)
-            out[:, a] = loc
-            if self.carry_hidden:
-                if mask is None:
-                    self.h[a], self.p[a] = h1, p1
-                else:
-                    m = mask.bool()
-                    self.h[a] = torch.where(m.view(-1, 1, 1), h1, self.h[a])
-                    self.p[a] = torch.where(m.view(-1, 1), p1, self.p[a])
+        (scaled coordinates).  `mask`: the envs this round counts for (bootstrap rounds); the others' rows are to be discarded.
+        All owners go through the same batched matrix products (PFGRUCell.forward's arithmetic, owner axis first)."""
+        A, N, P, H = self.A, self.N, self.P, self.H
+        W = self._stacked()
+        k_eps, k_res = self._key(1), self._key(2)                                                           # [A, N]
+        key = k_eps.view(A, N, 1, 1) * 1048583 + self._pu.view(1, 1, P, H)
+        u1, u2 = hash_uniform(key), hash_uniform(key + 2048)
+        eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()              # Box-Muller [A, N, P, H]
+        ru = hash_uniform(k_res.view(A, N, 1) * 1048583 + self._pu[:, 0].view(1, 1, P))                     # [A, N, P]
+        h0, p0 = self.h, self.p
+        x = obs[:, :, :3].permute(1, 0, 2).unsqueeze(2).expand(A, N, P, 3)                                  # owner a feeds its own row
+        cat = torch.cat((h0, x), dim=3).reshape(A, N * P, H + 3)
+        zr = torch.sigmoid(torch.baddbmm(W["zr_b"], cat, W["zr"])).view(A, N, P, 2 * H)
+        z, r = zr[..., :H], zr[..., H:]
+        n_1 = torch.baddbmm(W["n_b"], torch.cat((r * h0, x), dim=3).reshape(A, N * P, H + 3), W["n"]).view(A, N, P, 2 * H)
+        n = torch.tanh(n_1[..., :H] + eps * F.softplus(n_1[..., H:]))
+        h1 = (1 - z) * n + z * h0
+        logit = torch.baddbmm(W["o_b"], torch.cat((h1, x), dim=3).reshape(A, N * P, H + 3), W["o"]).view(A, N, P)
+        p1 = F.log_softmax(logit + p0, dim=2)
+        al = self.cells[0].resamp_alpha
+        cdf = torch.cumsum((al * torch.exp(p1) + (1 - al) / P).double(), dim=2)
+        cdf = cdf / cdf[..., -1:]
+        idx = torch.searchsorted(cdf.view(A * N, P), ru.view(A * N, P).contiguous(), right=True).clamp_(max=P - 1).view(A, N, P)
+        h1 = torch.gather(h1, 2, idx.unsqueeze(-1).expand(A, N, P, H))
+        pn = torch.exp(torch.gather(p1, 2, idx))
+        pn = torch.log(pn / (al * pn + (1 - al) / P))
+        p1 = pn - torch.logsumexp(pn, dim=2, keepdim=True)
+        mean_hid = torch.sum(torch.exp(p1).unsqueeze(-1) * h1, dim=2)                                       # [A, N, H]
+        loc = torch.relu(torch.baddbmm(W["h2_b"], torch.relu(torch.baddbmm(W["h0_b"], mean_hid, W["h0"])), W["h2"]))
+        if self.carry_hidden:
+            if mask is None:
+                self.h, self.p = h1, p1
+            else:
+                m = mask.bool()
+                self.h = torch.where(m.view(1, N, 1, 1), h1, self.h)
+                self.p = torch.where(m.view(1, N, 1), p1, self.p)
         self.calls = self.calls + (1 if mask is None else mask.long())
-        return out
+        return loc.permute(1, 0, 2).contiguous()
 
     def state_dict(self, a: int):
         return self.cells[a].state_dict()

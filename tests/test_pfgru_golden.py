@@ -130,3 +130,30 @@ def test_predictor_bank_is_sharding_invariant_and_deterministic():
         again2.load_state_dict(a, full.state_dict(a))
     again2.reset()
     assert torch.equal(first, again2.predict(obs))                   # the same seed reproduces them
+
+
+def test_bank_batched_over_owners_equals_the_cell():
+    """PredictorBank.predict runs all owners through stacked matrix products; owner by owner it must equal PFGRUCell.forward
+    (the function pinned to the reference above) on the same draws."""
+    import math
+    torch.manual_seed(3)
+    bank = PredictorBank(6, 3, seed=11, env_id_base=40, device="cpu")
+    rng = np.random.default_rng(2)
+    obs = torch.from_numpy(rng.uniform(0, 1.5, (6, 3, 11)).astype(np.float32))
+    bank.reset()
+    h0, p0 = bank.h.clone(), bank.p.clone()
+    k_eps, k_res = bank._key(1), bank._key(2)
+    got = bank.predict(obs)
+    for a in range(3):
+        key = k_eps[a].view(6, 1, 1) * 1048583 + bank._pu.view(1, 40, 24)
+        u1, u2 = hash_uniform(key), hash_uniform(key + 2048)
+        eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()
+        ru = hash_uniform(k_res[a].view(6, 1) * 1048583 + bank._pu[:, 0].view(1, 40))
+        with torch.no_grad():
+            want, _ = bank.cells[a](obs[:, a, :3].contiguous(), (h0[a], p0[a]), eps, resample_u=ru)
+        assert torch.allclose(got[:, a], want, rtol=1e-5, atol=1e-6), a
+    # new weights are picked up (the stacked copies are rebuilt)
+    sd = {k: v * 1.5 for k, v in bank.state_dict(1).items()}
+    bank.load_state_dict(1, sd)
+    bank.reset()
+    assert not torch.allclose(bank.predict(obs)[:, 1], got[:, 1])
