@@ -296,6 +296,28 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
                           int64_t num_samples, const float* w2, const float* da2, const uint16_t* relu_mask, const float* p1,
                           const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream);
 
+/* ---- PFGRU location predictor -------------------------------------------------------------
+ * One forward step of `self.model(obs_tensor, hidden)` in CNNBase.select_action (algos/test_cnn/RADTEAM_core.py:1872-1879):
+ * PFGRUCell.forward (:1586-1631) = GRU-style particle update with reparameterised noise (:1517-1530), observation
+ * likelihood + log-softmax (:1633-1641), soft resampling (:1466-1515), weighted particle mean -> hid_obs MLP (:1574-1584),
+ * for every (owner, env) at once: 40 particles x 24 hidden units.
+ *   weights   [A][RS_PFGRU_WEIGHT_FLOATS]  per-owner packed parameters (layout: csrc/rs_pfgru.hip; packer: pfgru.py)
+ *   obs       [N][A][11]   the owner's own row supplies (reading, x, y)
+ *   h, p      [A][N][40][24] particles, [A][N][40] log weights; read; written back when carry_hidden != 0 (mask[n] != 0)
+ *   base_key  [A][N], episode [N], calls [N]   counters of the draw hash (documented RNG deviation: the reference draws
+ *             from torch's global generator)
+ *   pred      [N][A][2]    location prediction (scaled coordinates, >= 0: the reference's MLP ends in a ReLU) */
+#define RS_PFGRU_PARTICLES 40
+#define RS_PFGRU_HIDDEN 24
+#define RS_PFGRU_WEIGHT_FLOATS 3376
+int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
+                  const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
+                  int32_t num_agents, rs_stream_t stream);
+/* reset_hidden (RADTEAM_core.py:2030-2033, PFGRUCell.init_hidden :1643-1652) for the envs with mask[n] != 0 (all when null):
+ * h0 ~ U[0,1) from the draw hash, p0 = log(1/40).  episode[] / calls[] must already count the new episode. */
+int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
+                   int32_t num_envs, int32_t num_agents, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,6 +296,28 @@ __device__ __forceinline__ double rs_dist_pt_axis_seg(int px, int py, int ax, in
     return rs_dist_i(px, py, cx, cy);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cooperative env step: CN lanes of a wave (lane = slot + 16*cj, cj = 0..CN-1) run the SAME env.  Every lane executes the
+// whole step redundantly on identical inputs (so control flow agrees inside the group); only the obstacle loops --
+// the vertex loop of the shortest path, the rectangle loops, the eight probe directions -- are split by cj and
+// combined with exact, order-independent reductions (min / or / integer sum).  Results are bit-identical to CN = 1.
+template <int CN> __device__ __forceinline__ bool rs_grp_any(bool b) {
+    if (CN == 1) return b;
+    int v = b ? 1 : 0;
+    v |= __shfl_xor(v, 16); v |= __shfl_xor(v, 32);
+    return v != 0;
+}
+template <int CN> __device__ __forceinline__ int rs_grp_sum(int v) {
+    if (CN == 1) return v;
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+template <int CN> __device__ __forceinline__ double rs_grp_min(double v) {
+    if (CN == 1) return v;
+    v = fmin(v, __shfl_xor(v, 16)); v = fmin(v, __shfl_xor(v, 32));
+    return v;
+}
+
 __device__ __forceinline__ bool rs_visible(const RsGeo& g, int px, int py, int qx, int qy) {
     for (int o = 0; o < g.n; ++o) {
         int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
@@ -306,28 +328,64 @@ __device__ __forceinline__ bool rs_visible(const RsGeo& g, int px, int py, int q
 
 // world.shortest_path(source, detector).length() (:491-493): Euclid when visible, else best detour
 // through a rectangle vertex whose geodesic distance from the source was cached at reset.
+template <int CN>
 __device__ __forceinline__ double rs_shortest_path(const RsGeo& g, const double* dsrc, int N, int n,
-                                                   int sx, int sy, int px, int py) {
-    if (rs_visible(g, sx, sy, px, py)) return rs_dist_i(sx, sy, px, py);
-    double best = INFINITY;
-    for (int v = 0; v < 4 * g.n; ++v) {
-        double d = dsrc[(size_t)v * N + n];
-        if (d < best) {                       // exact prune: d + |v-p| >= d, a vertex at d >= best cannot improve
-            int vx, vy; g.vertex(v, vx, vy);
-            const double c = d + rs_dist_i(vx, vy, px, py);
-            if (c < best && rs_visible(g, vx, vy, px, py)) best = c;     // visibility only for improving candidates
+                                                   int sx, int sy, int px, int py, int cj) {
+    if (CN == 1) {
+        if (rs_visible(g, sx, sy, px, py)) return rs_dist_i(sx, sy, px, py);
+    } else {
+        bool hit = false;
+        for (int o = cj; o < g.n; o += CN) {
+            int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+            hit |= rs_seg_hits_open_rect(sx, sy, px, py, x0, y0, x1, y1);
         }
+        if (!rs_grp_any<CN>(hit)) return rs_dist_i(sx, sy, px, py);
+    }
+    double best = INFINITY;
+    if (CN == 1) {
+        for (int v = 0; v < 4 * g.n; ++v) {
+            double d = dsrc[(size_t)v * N + n];
+            if (d < best) {                       // exact prune: d + |v-p| >= d, a vertex at d >= best cannot improve
+                int vx, vy; g.vertex(v, vx, vy);
+                const double c = d + rs_dist_i(vx, vy, px, py);
+                if (c < best && rs_visible(g, vx, vy, px, py)) best = c;     // visibility only for improving candidates
+            }
+        }
+    } else {
+        // this lane's vertices: corner cj of every rectangle; the cached geodesics are fetched up front (one latency)
+        double dv[RS_MAX_VERT / 4];
+#pragma unroll
+        for (int o = 0; o < RS_MAX_VERT / 4; ++o) dv[o] = (o < g.n) ? dsrc[(size_t)(4 * o + cj) * N + n] : INFINITY;
+#pragma unroll
+        for (int o = 0; o < RS_MAX_VERT / 4; ++o) {
+            if (o < g.n && dv[o] < best) {
+                int vx, vy; g.vertex(4 * o + cj, vx, vy);
+                const double c = dv[o] + rs_dist_i(vx, vy, px, py);
+                if (c < best && rs_visible(g, vx, vy, px, py)) best = c;
+            }
+        }
+        best = rs_grp_min<CN>(best);
     }
     return best;
 }
 
 // is_intersect (:1133-1146) for a detector at (px,py)
-__device__ __forceinline__ bool rs_is_intersect(const RsGeo& g, int px, int py, int sx, int sy, double euc, double sp) {
-    for (int o = 0; o < g.n; ++o) {
-        int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
-        if (rs_seg_rect_close(px, py, sx, sy, x0, y0, x1, y1) && !rs_isclose_abs(sqrt(euc), sp, 0.1)) return true;
+template <int CN>
+__device__ __forceinline__ bool rs_is_intersect(const RsGeo& g, int px, int py, int sx, int sy, double euc, double sp, int cj) {
+    if (CN == 1) {
+        for (int o = 0; o < g.n; ++o) {
+            int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+            if (rs_seg_rect_close(px, py, sx, sy, x0, y0, x1, y1) && !rs_isclose_abs(sqrt(euc), sp, 0.1)) return true;
+        }
+        return false;
     }
-    return false;
+    if (rs_isclose_abs(sqrt(euc), sp, 0.1)) return false;        // the second operand of the `and` does not depend on the rectangle
+    bool close = false;
+    for (int o = cj; o < g.n; o += CN) {
+        int x0, y0, x1, y1; g.rect(o, x0, y0, x1, y1);
+        close |= rs_seg_rect_close(px, py, sx, sy, x0, y0, x1, y1);
+    }
+    return rs_grp_any<CN>(close);
 }
 
 // in_obstruction (:1148-1170): first rectangle that contains the point (closed), then strict test on it
@@ -347,8 +405,9 @@ __device__ __forceinline__ bool rs_pt_in_closed_eps(double qx, double qy, int x0
 
 // obstruction_sensors (:1172-1261) + correct_coords (:1263-1306).  Writes the 8 readings (float64
 // values rounded once to float32, as the PPO buffer does) to out[0..7] (an LDS row).
-template <bool HAS_OBS>
-__device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, int px, int py, float* out, uint32_t& err) {
+template <bool HAS_OBS, int CN = 1>
+__device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, int px, int py, float* out, uint32_t& err, int cj = 0) {
+    uint32_t mine = 0xffu;     // directions whose reading this lane holds (CN > 1: two probe directions per lane)
     double d8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) d8[i] = 0.0;
@@ -365,8 +424,10 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
     if (HAS_OBS && near != 0) {
         uint64_t cnt = 0;      // obs_idx_ls packed 8 bits per obstacle
         int ones = 0;
+        if (CN > 1) mine = 3u << (2 * cj);
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) {
+            if (CN > 1 && !(mine >> idx & 1u)) continue;
             int sx_, sy_; rs_action_step(idx, sx_, sy_);
             int qx = px + sx_, qy = py + sy_;
             int inter = 0;
@@ -395,7 +456,13 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
             d8[idx] = dmax;
             ones += (dmax == 1.0) ? 1 : 0;
         }
+        if (CN > 1) {          // integer sums over the group: per-obstacle hit counts stay below 256 (8 probes x 2 edges)
+            ones = rs_grp_sum<CN>(ones);
+            const int lo = rs_grp_sum<CN>((int)(uint32_t)cnt), hi = rs_grp_sum<CN>((int)(uint32_t)(cnt >> 32));
+            cnt = (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+        }
         if (ones > 3) {
+            mine = 0xffu;      // every lane recomputes all eight readings from the same inputs
             // argmax = max(zip(obs_idx_ls, self.poly))[1]: count, then vertex list lexicographically
             int best = 0;
             for (int k = 1; k < g.n; ++k) {
@@ -439,7 +506,8 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (float)d8[i];
+    for (int i = 0; i < 8; ++i)
+        if (CN == 1 || (mine >> i & 1u)) out[i] = (float)d8[i];
     if (P.enforce) {
         // walls (:1232-1259): (DIST_TH - |x - wall|) / DIST_TH with an integer distance 0..110 -> exact table
         const int dl = abs(px - P.bx0), dd = abs(py - P.by0), dr = abs(P.bx1 - px), du = abs(P.by1 - py);
@@ -467,9 +535,12 @@ struct RsOut {
 // RadSearch.step for env n (one lane).  act_of(a) returns agent a's action (0..8) or RS_ACT_NONE.
 // Mirrors step :443-728 / agent_step :460-613; agents are processed in id order because `done`, the
 // team reward and the collision rule are order dependent.
-template <bool HAS_OBS, typename ActFn>
+// CN > 1: the cooperative form (see rs_grp_any): lanes cj = 0..CN-1 of a group call this with the same n, g, actions and O.
+// Every lane of the group stores the (identical) results: duplicate addresses inside one store instruction cost nothing,
+// and each lane's later loads of the env state are then ordered after its OWN stores, which the language guarantees.
+template <bool HAS_OBS, int CN = 1, typename ActFn>
 __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo& g, int n, ActFn act_of, const RsOut& O,
-                                                 bool no_collision_rule = false) {
+                                                 bool no_collision_rule = false, int cj = 0) {
     const int N = P.N, A = P.A;
     const int sx = P.src_x[n], sy = P.src_y[n];
     const int intensity = P.intensity[n], bkg = P.bkg[n];
@@ -534,13 +605,13 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
 #if defined(RS_ABL) && RS_ABL == 3
         if (moved) sp = euc;
 #else
-        if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, sx, sy, x, y) : euc;
+        if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path<CN>(g, P.dsrc, N, n, sx, sy, x, y, cj) : euc;
 #endif
         if (HAS_OBS && !(sp < INFINITY)) err |= RS_ENVERR_NO_PATH;
 #if defined(RS_ABL) && RS_ABL == 2
         bool inter = false;
 #else
-        bool inter = (HAS_OBS && g.n > 0) ? rs_is_intersect(g, px, py, sx, sy, euc, sp) : false;
+        bool inter = (HAS_OBS && g.n > 0) ? rs_is_intersect<CN>(g, px, py, sx, sy, euc, sp, cj) : false;
 #endif
         fl = (uint8_t)((fl & ~RS_AF_INTERSECT) | (inter ? RS_AF_INTERSECT : 0));
         double lam;
@@ -565,7 +636,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
         row[0] = (float)(double)meas;
         row[1] = (float)(((double)x + 0.0) * P.scale);
         row[2] = (float)(((double)y + 0.0) * P.scale);
-        if ((HAS_OBS && g.n > 0) || P.enforce) rs_sensors<HAS_OBS>(P, g, px, py, row + 3, err);
+        if ((HAS_OBS && g.n > 0) || P.enforce) rs_sensors<HAS_OBS, CN>(P, g, px, py, row + 3, err, cj);
         else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) row[3 + i] = 0.0f;
@@ -686,50 +757,72 @@ __device__ __forceinline__ bool rs_layout_valid(const int* lds_geo, int stride, 
 
 // Geodesic distance source -> every rectangle vertex (visibility graph relaxation in per-wave LDS scratch), cached
 // in P.dsrc for the episode: rs_shortest_path then needs one visibility test per candidate vertex.
-template <bool HAS_OBS>
+template <bool HAS_OBS, int CN = 1>
 __device__ __forceinline__ void rs_source_geodesics(const RsParams& P, const RsGeo& g, int n, int srx, int sry,
-                                                    uint32_t* lds_adj, double* lds_d) {
-    const int lane = threadIdx.x & 63;
+                                                    uint32_t* lds_adj, double* lds_d, int slot, int cj = 0) {
+    // slot: the env's column of the per-wave scratch.  CN > 1: the lanes of the group take the vertices v = cj (mod CN);
+    // visibility is symmetric, so a lane tests only the pairs u < v and the rows are completed from the columns.  The
+    // relaxation is order independent: fl(d + w) is monotone in d, so any fair sequence of relaxations descends to the
+    // same least fixed point (= the minimum over paths of the left-to-right float64 path sums); it runs until no lane of
+    // the group changes a distance.
     const int N = P.N;
     const int V = HAS_OBS ? 4 * g.n : 0;
-    for (int v = 0; v < V; ++v) {
+    for (int v = cj; v < V; v += CN) {
         int vx, vy; g.vertex(v, vx, vy);
-        lds_d[v * RS_WAVE + lane] = rs_visible(g, srx, sry, vx, vy) ? rs_dist_i(srx, sry, vx, vy) : INFINITY;
+        lds_d[v * RS_WAVE + slot] = rs_visible(g, srx, sry, vx, vy) ? rs_dist_i(srx, sry, vx, vy) : INFINITY;
         uint32_t m = 0;
-        for (int u = 0; u < V; ++u) {
-            if (u == v) continue;
+        for (int u = 0; u < v; ++u) {
             int ux, uy; g.vertex(u, ux, uy);
             if (rs_visible(g, ux, uy, vx, vy)) m |= 1u << u;
         }
-        lds_adj[v * RS_WAVE + lane] = m;
+        lds_adj[v * RS_WAVE + slot] = m;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t mine[(RS_MAX_VERT + CN - 1) / CN];      // full adjacency rows of this lane's vertices
+#pragma unroll
+    for (int i = 0; i < (RS_MAX_VERT + CN - 1) / CN; ++i) {
+        const int v = cj + i * CN;
+        uint32_t m = 0;
+        if (v < V) {
+            m = lds_adj[v * RS_WAVE + slot];
+            for (int u = v + 1; u < V; ++u) m |= ((lds_adj[u * RS_WAVE + slot] >> v) & 1u) << u;
+        }
+        mine[i] = m;
     }
     bool changed = V > 0;
     while (changed) {
         changed = false;
-        for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int i = 0; i < (RS_MAX_VERT + CN - 1) / CN; ++i) {
+            const int v = cj + i * CN;
+            if (v >= V) continue;
             int vx, vy; g.vertex(v, vx, vy);
-            uint32_t m = lds_adj[v * RS_WAVE + lane];
-            double dv = lds_d[v * RS_WAVE + lane];
-            for (int u = 0; u < V; ++u) {
-                if (!(m >> u & 1u)) continue;
+            const uint32_t m = mine[i];
+            double dv = lds_d[v * RS_WAVE + slot];
+            for (uint32_t rem = m; rem != 0; rem &= rem - 1) {
+                const int u = __ffs((int)rem) - 1;
                 int ux, uy; g.vertex(u, ux, uy);
-                double c = lds_d[u * RS_WAVE + lane] + rs_dist_i(ux, uy, vx, vy);
+                double c = lds_d[u * RS_WAVE + slot] + rs_dist_i(ux, uy, vx, vy);
                 if (c < dv) { dv = c; changed = true; }
             }
-            lds_d[v * RS_WAVE + lane] = dv;
+            lds_d[v * RS_WAVE + slot] = dv;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        changed = rs_grp_any<CN>(changed);
     }
-    for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + lane];
+    for (int v = 0; v < V; ++v) P.dsrc[(size_t)v * N + n] = lds_d[v * RS_WAVE + slot];
 }
 
 // ---------------------------------------------------------------------------------------------
 // RadSearch.reset for env n (one lane): rad_search_env.py:730-797 with create_obs (per-env layouts),
 // sample_source_loc_pos :1013-1131, the source->vertex geodesic cache, and the initial step(None).
 // lds_adj / lds_d: per-wave scratch [28][64] (u32 / f64), only touched when HAS_OBS.
-template <bool HAS_OBS>
+// CN > 1: cooperative form (see rs_grp_any): the CN lanes of a group call this together with slot = the env's LDS column;
+// draws, rejection loops and stores are replicated (identical in every lane), the geodesic cache and the first step split.
+template <bool HAS_OBS, int CN = 1>
 __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, int n, int* lds_geo, uint32_t* lds_adj,
-                                                  double* lds_d, float* obs_row, const RsOut& O) {
-    const int lane = threadIdx.x & 63;
+                                                  double* lds_d, float* obs_row, const RsOut& O, int slot = -1, int cj = 0) {
+    const int lane = (slot >= 0) ? slot : (int)(threadIdx.x & 63);
     const int N = P.N, A = P.A;
     const uint32_t episode = P.episode[n];
     RsDrawSeq seq{P.seed, P.env_id_base + (uint32_t)n, episode, RS_STREAM_RESET, 0u};
@@ -787,8 +880,8 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
         P.num_obs[n] = g.n;
         for (int w = 0; w < 4 * g.n; ++w) P.rect[(size_t)w * P.G + n] = lds_geo[w * RS_WAVE + lane];
     }
-    rs_source_geodesics<HAS_OBS>(P, g, n, srx, sry, lds_adj, lds_d);
-    double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
+    rs_source_geodesics<HAS_OBS, CN>(P, g, n, srx, sry, lds_adj, lds_d, lane, cj);
+    double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path<CN>(g, P.dsrc, N, n, srx, sry, dtx, dty, cj) : rs_dist_i(srx, sry, dtx, dty);
     // ---- state write (Agent.reset :292-301, reset :736-742, :771-776)
     P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = intensity; P.bkg[n] = bkg;
     P.done[n] = 0; P.iter_count[n] = 0; P.tstep[n] = 0;
@@ -801,7 +894,7 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     o.obs_row = obs_row;
     P.episode[n] = episode + 1;       // draws of this episode are keyed by `episode`
     for (int k = 0; k <= extra_idle; ++k) {
-        rs_env_step_lane<HAS_OBS>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o);
+        rs_env_step_lane<HAS_OBS, CN>(P, g, n, [](int) -> int { return RS_ACT_NONE; }, o, false, cj);
         P.iter_count[n] = 0;
     }
 }
@@ -847,8 +940,8 @@ __device__ __forceinline__ void rs_env_refresh_lane(const RsParams& P, RsGeo& g,
     }
     P.epoch_end[n] = 0;                                                   // :810
     const int srx = R.src[2 * n], sry = R.src[2 * n + 1], dtx = R.det[2 * n], dty = R.det[2 * n + 1];
-    rs_source_geodesics<HAS_OBS>(P, g, n, srx, sry, lds_adj, lds_d);
-    const double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path(g, P.dsrc, N, n, srx, sry, dtx, dty) : rs_dist_i(srx, sry, dtx, dty);
+    rs_source_geodesics<HAS_OBS>(P, g, n, srx, sry, lds_adj, lds_d, lane);
+    const double prev = (HAS_OBS && g.n > 0) ? rs_shortest_path<1>(g, P.dsrc, N, n, srx, sry, dtx, dty, 0) : rs_dist_i(srx, sry, dtx, dty);
     P.src_x[n] = srx; P.src_y[n] = sry; P.intensity[n] = R.intensity[n]; P.bkg[n] = R.bkg[n];
     P.done[n] = 0; P.iter_count[n] = 0; P.tstep[n] = 0;                   // :811-812
     for (int a = 0; a < A; ++a) {                                         // Agent.reset + det_coords (:823-826)

@@ -5,6 +5,7 @@
 // L2 of the XCD its block lands on from launch to launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -48,6 +49,53 @@ __global__ void __launch_bounds__(64, (HAS_OBS ? 4 : 1)) rs_step_kernel(RsParams
     rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);
 }
 
+// K1 with obstacles: 16 envs per wave, four lanes per env (lane = slot + 16*cj).  The step of an env behind an obstacle is a
+// long serial chain (up to 28 rectangle vertices x 7 rectangles of exact segment tests, 8 probe directions); with one env
+// per lane a wave waits for its slowest lane while 8192 envs are only 128 waves on 256 CUs.  Here the four lanes split
+// those loops (rs_env_step_lane<true, 4>), and 8192 envs are 512 waves.  Bit-identical to the one-lane form.
+__global__ void __launch_bounds__(64, 2) rs_step4_kernel(RsParams P, const int8_t* __restrict__ actions, float* obs, RsOut O) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* lds_geo = reinterpret_cast<int*>(smem);
+    float* tile = reinterpret_cast<float*>(smem + RS_MAX_VERT * RS_WAVE * 4);
+    const int lane = threadIdx.x & 63, slot = lane & 15, cj = lane >> 4;
+    const int n = blockIdx.x * 16 + slot;
+    const bool active = n < P.N;
+    const int gi = active ? n / P.group : 0;
+    int no = active ? P.num_obs[gi] : 0;
+    for (int w = cj; w < 4 * no; w += 4) lds_geo[w * RS_WAVE + slot] = P.rect[(size_t)w * P.G + gi];
+    if (P.uniform_nobs > 0 && active) no = P.uniform_nobs;
+    RsGeo g{lds_geo, RS_WAVE, slot, no};
+    __syncthreads();
+    const int S = rs_tile_stride(P.A);
+    if (active) {
+        RsOut o = O;
+        o.obs_row = tile + slot * S;
+        const int8_t* arow = actions + (size_t)n * P.A;
+        uint32_t bad = 0;
+        bool single_int = false;
+        for (int a = 0; a < P.A; ++a) single_int |= arow[a] >= 16;
+        auto act_of = [&](int a) -> int {
+            int v = arow[a];
+            if (v >= 16) v -= 16;
+            if (v == -1) return RS_IDLE;
+            if (v < 0 || v > RS_ACT_NONE) { bad = RS_ENVERR_BAD_ACTION; return RS_IDLE; }
+            return v;
+        };
+        rs_env_step_lane<true, 4>(P, g, n, act_of, o, single_int, cj);
+        if (bad && cj == 0) P.err[n] |= bad;
+    }
+    __syncthreads();
+    if (obs) {
+        const int row = P.A * RS_OBS_DIM;
+        const int rows = min(16, P.N - blockIdx.x * 16);
+        float* dst = obs + (size_t)blockIdx.x * 16 * row;
+        for (int i = lane; i < rows * row; i += RS_WAVE) {
+            const int l = i / row, k = i - l * row;
+            dst[i] = tile[l * S + k];
+        }
+    }
+}
+
 // K2a: obstacle layouts shared by a group of envs (geom_group_size > 1): one lane per group.
 __global__ void __launch_bounds__(64) rs_geom_kernel(RsParams P, const uint8_t* __restrict__ mask) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -89,6 +137,41 @@ __global__ void __launch_bounds__(64) rs_reset_kernel(RsParams P, const uint8_t*
     }
     __syncthreads();
     rs_copy_out(P, obs, tile, flags, blockIdx.x * blockDim.x);
+}
+
+// K2 with obstacles, four lanes per env (see rs_step4_kernel): the visibility graph behind the geodesic cache (up to 28 x 27 / 2
+// vertex pairs x 7 rectangles of exact segment tests) and its relaxation are split over the group.
+__global__ void __launch_bounds__(64) rs_reset4_kernel(RsParams P, const uint8_t* __restrict__ mask, float* obs, RsOut O) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* lds_geo = reinterpret_cast<int*>(smem);
+    uint32_t* lds_adj = reinterpret_cast<uint32_t*>(smem + RS_MAX_VERT * RS_WAVE * 4);
+    double* lds_d = reinterpret_cast<double*>(smem + 2 * RS_MAX_VERT * RS_WAVE * 4);
+    float* tile = reinterpret_cast<float*>(smem + 2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8);
+    const int S = rs_tile_stride(P.A);
+    int* flags = reinterpret_cast<int*>(tile + RS_WAVE * S);
+    const int lane = threadIdx.x & 63, slot = lane & 15, cj = lane >> 4;
+    const int n = blockIdx.x * 16 + slot;
+    const bool active = n < P.N && (mask == nullptr || mask[n] != 0);
+    RsGeo g{lds_geo, RS_WAVE, slot, 0};
+    if (P.group > 1 && active) {                       // shared layouts were resampled by rs_geom_kernel
+        const int gi = n / P.group;
+        g.n = P.num_obs[gi];
+        for (int w = cj; w < 4 * g.n; w += 4) lds_geo[w * RS_WAVE + slot] = P.rect[(size_t)w * P.G + gi];
+        if (P.uniform_nobs > 0) g.n = P.uniform_nobs;
+    }
+    flags[slot] = active ? 1 : 0;
+    __syncthreads();
+    if (active) rs_env_reset_lane<true, 4>(P, g, n, lds_geo, lds_adj, lds_d, tile + slot * S, O, slot, cj);
+    __syncthreads();
+    if (obs) {
+        const int row = P.A * RS_OBS_DIM;
+        const int rows = min(16, P.N - blockIdx.x * 16);
+        float* dst = obs + (size_t)blockIdx.x * 16 * row;
+        for (int i = lane; i < rows * row; i += RS_WAVE) {
+            const int l = i / row, k = i - l * row;
+            if (flags[l]) dst[i] = tile[l * S + k];
+        }
+    }
 }
 
 // K2b: RadSearch.refresh_environment for the masked envs (rad_search_env.py:799-874)
@@ -344,7 +427,9 @@ int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float
         hipLaunchKernelGGL(rs_geom_kernel, dim3((P.G + 63) / 64), dim3(64), RS_MAX_VERT * RS_WAVE * 4, s, P, mask);
     }
     size_t lds = tile_bytes(P.A) + (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
-    if (has_obs) hipLaunchKernelGGL(rs_reset_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
+    static const bool one_lane = getenv("RS_STEP_ONE_LANE") != nullptr;       // A/B switch: the one-env-per-lane obstacle kernels
+    if (has_obs && !one_lane) hipLaunchKernelGGL(rs_reset4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
+    else if (has_obs) hipLaunchKernelGGL(rs_reset_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_reset_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
@@ -371,7 +456,9 @@ int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RsParams& P = h->P;
     size_t lds = tile_bytes(P.A) + (P.obstruction_count != 0 ? RS_MAX_VERT * RS_WAVE * 4 : 0);
-    if (P.obstruction_count != 0) hipLaunchKernelGGL(rs_step_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
+    static const bool one_lane = getenv("RS_STEP_ONE_LANE") != nullptr;       // A/B switch: the one-env-per-lane obstacle step
+    if (P.obstruction_count != 0 && !one_lane) hipLaunchKernelGGL(rs_step4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
+    else if (P.obstruction_count != 0) hipLaunchKernelGGL(rs_step_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_step_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

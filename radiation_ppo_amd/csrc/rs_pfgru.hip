@@ -1,0 +1,258 @@
+// rs_pfgru.hip -- K11: one forward step of the PFGRU location predictor for every (owner, env).
+//
+// Replaces `self.model(obs_tensor, hidden)` of CNNBase.select_action (algos/test_cnn/RADTEAM_core.py:1872-1879), i.e.
+// PFGRUCell.forward (:1586-1631) with observation_likelihood (:1633-1641), soft resampling (PFRNNBaseCell.resampling
+// :1466-1515) and reparameterize (:1517-1530): 40 particles x 24 hidden units, alpha 0.7, tanh.
+//
+// Mapping: one wave per (owner, env), one particle per lane (40 of 64 lanes).  A particle's 24 hidden units, its gates and
+// its candidate state live in the lane's registers; the three small matrix products (27 -> 48, 27 -> 48, 27 -> 1) are
+// per-lane FMA chains whose weights are wave-uniform (one owner per wave): they arrive through the scalar unit
+// (s_load_dwordx16 from the constant address space -> SGPR operand of v_fma), costing neither VGPRs nor LDS bandwidth.
+// What couples the particles -- log-softmax, the resampling CDF, the gather of resampled particles, the weighted mean --
+// goes through wave reductions and a 4.6 KB per-wave LDS tile.  Random draws (reparameterisation noise, resampling
+// uniforms) are the counter hash of radiation_ppo_amd/pfgru.py evaluated in the kernel: nothing is read but the
+// observation row, the particle set (3.9 KB) and the 13.5 KB of weights (L2 / scalar cache resident).
+//
+// Bound: VALU issue (2 700 FMAs + 24 hashes + ~120 transcendentals per lane); 16 384 waves per step at config 4.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/radsearch.h"
+
+namespace {
+
+constexpr int PF_P = RS_PFGRU_PARTICLES, PF_H = RS_PFGRU_HIDDEN, PF_IN = 3, PF_K = PF_H + PF_IN;   // 40, 24, 3, 27
+// packed weights of one owner (floats), produced on the host (radiation_ppo_amd/pfgru.py: pack_weights):
+//   zr_t [27][48] (k-major; outputs 0..23 = fc_z, 24..47 = fc_r) | zr_b [48] | n_t [27][48] (0..23 mu, 24..47 var) | n_b [48]
+//   | o_w [27] | o_b [1] | pad to 16 | h0_t [24][24] (k-major) | h0_b [24] | h2_w [2][24] | h2_b [2] | pad
+constexpr int PF_ZR = 0, PF_ZRB = PF_ZR + PF_K * 48, PF_N = PF_ZRB + 48, PF_NB = PF_N + PF_K * 48, PF_O = PF_NB + 48,
+              PF_OB = PF_O + PF_K, PF_H0 = ((PF_OB + 1 + 15) / 16) * 16, PF_H0B = PF_H0 + PF_H * 24, PF_H2 = PF_H0B + 24,
+              PF_H2B = PF_H2 + 48, PF_STRIDE = ((PF_H2B + 2 + 15) / 16) * 16;
+static_assert(PF_STRIDE == RS_PFGRU_WEIGHT_FLOATS, "include/radsearch.h: RS_PFGRU_WEIGHT_FLOATS");
+
+typedef const float __attribute__((address_space(4))) * cmem_t;
+__device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
+
+// splitmix64 finaliser on wrapping 64-bit arithmetic == pfgru.py: hash_bits
+__device__ __forceinline__ uint64_t pf_hash(uint64_t key) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+struct PfArgs {
+    const float* w;           // [A][PF_STRIDE]
+    const float* obs;         // [N][A][11]
+    float* h;                 // [A][N][P][H]
+    float* p;                 // [A][N][P]
+    const int64_t* base;      // [A][N]  per (owner, env) key
+    const int64_t* episode;   // [N]
+    const int64_t* calls;     // [N]
+    const uint8_t* mask;      // [N] or null: envs whose carried state is updated
+    float* pred;              // [N][A][2]
+    int N, A, carry;
+    float alpha, floor_;      // soft-resampling alpha and (1 - alpha) / P, rounded to float32 as torch does for scalars
+};
+
+constexpr int PF_ROW = PF_H + 1;                                   // odd row stride: conflict-free row writes and column reads
+constexpr int PF_LDS_WAVE = PF_P * PF_ROW * 4 + PF_P * 8 + 64 * 4; // h tile, cdf (f64), p1 / mean
+
+__global__ void __launch_bounds__(256) rs_pfgru_kernel(PfArgs a_) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wv = (long long)blockIdx.x * 4 + wid;
+    if (wv >= (long long)a_.A * a_.N) return;                       // whole waves only: no barrier below
+    const int own = __builtin_amdgcn_readfirstlane((int)(wv / a_.N));
+    const int n = __builtin_amdgcn_readfirstlane((int)(wv - (long long)own * a_.N));
+    unsigned char* base = smem + (size_t)wid * PF_LDS_WAVE;
+    float* tile = reinterpret_cast<float*>(base);                   // [P][PF_ROW]
+    double* cdf = reinterpret_cast<double*>(base + PF_P * PF_ROW * 4);
+    float* vec = reinterpret_cast<float*>(base + PF_P * PF_ROW * 4 + PF_P * 8);   // [64]
+
+    const bool act = lane < PF_P;
+    const int pl = act ? lane : PF_P - 1;                           // idle lanes shadow the last particle (values discarded)
+    cmem_t W = as_cmem(a_.w + (size_t)own * PF_STRIDE);
+    const size_t slot = (size_t)own * a_.N + n;
+    const float* hp = a_.h + (slot * PF_P + pl) * PF_H;
+    float h0[PF_H];
+#pragma unroll
+    for (int u = 0; u < PF_H; u += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(hp + u);
+        h0[u] = v.x; h0[u + 1] = v.y; h0[u + 2] = v.z; h0[u + 3] = v.w;
+    }
+    const float p0 = a_.p[slot * PF_P + pl];
+    float x[PF_IN];
+    {
+        cmem_t o = as_cmem(a_.obs + ((size_t)n * a_.A + own) * RS_OBS_DIM);
+#pragma unroll
+        for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
+    }
+    // keys (pfgru.py: PredictorBank._key): kind 1 = reparameterisation noise, 2 = resampling uniforms
+    const uint64_t kb = (uint64_t)a_.base[slot] * 1000003ull;
+    const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n]) * 8ull;
+    const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
+    const uint64_t k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
+    const uint64_t pk = k_eps * 1048583ull + (uint64_t)pl * 4096ull;
+
+    // ---- gates: z | r = sigmoid(W_zr [h0, x] + b)
+    float g[48];
+#pragma unroll
+    for (int o = 0; o < 48; ++o) g[o] = W[PF_ZRB + o];
+#pragma unroll
+    for (int k = 0; k < PF_K; ++k) {
+        const float c = (k < PF_H) ? h0[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H];
+#pragma unroll
+        for (int o = 0; o < 48; ++o) g[o] = fmaf(W[PF_ZR + k * 48 + o], c, g[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 48; ++o) g[o] = 1.0f / (1.0f + expf(-g[o]));
+    // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b
+    float m[48];
+#pragma unroll
+    for (int o = 0; o < 48; ++o) m[o] = W[PF_NB + o];
+#pragma unroll
+    for (int k = 0; k < PF_K; ++k) {
+        const float c = (k < PF_H) ? g[24 + (k < PF_H ? k : 0)] * h0[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H];
+#pragma unroll
+        for (int o = 0; o < 48; ++o) m[o] = fmaf(W[PF_N + k * 48 + o], c, m[o]);
+    }
+    float h1[PF_H];
+#pragma unroll
+    for (int u = 0; u < PF_H; ++u) {
+        const uint64_t hx = pf_hash(pk + (uint64_t)u);
+        const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
+        const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
+        const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.2831855f * u2);                   // Box-Muller
+        const float var = m[24 + u];
+        const float sp = (var > 20.0f) ? var : log1pf(expf(var));                            // F.softplus
+        const float nv = tanhf(m[u] + eps * sp);
+        h1[u] = (1.0f - g[u]) * nv + g[u] * h0[u];
+    }
+    // ---- observation likelihood, log-softmax over the particles
+    float lg = W[PF_OB];
+#pragma unroll
+    for (int k = 0; k < PF_K; ++k) lg = fmaf(W[PF_O + k], (k < PF_H) ? h1[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H], lg);
+    lg += p0;
+    const float mx = wave_max(act ? lg : -INFINITY);
+    const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
+    float p1 = (lg - mx) - logf(se);
+    // ---- soft resampling: indices by inverse CDF of alpha * w + (1 - alpha) / P
+    const float al = a_.alpha, floor_ = a_.floor_;
+    {
+        double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {                         // inclusive scan over the lanes (float64)
+            const double t = __shfl_up(c, s);
+            if (lane >= s) c += t;
+        }
+        const double tot = __shfl(c, PF_P - 1);
+        if (act) cdf[lane] = c / tot;
+#pragma unroll
+        for (int u = 0; u < PF_H; ++u) if (act) tile[lane * PF_ROW + u] = h1[u];
+        vec[lane] = p1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)pl * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
+    int idx = 0;
+    for (int q = 0; q < PF_P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;  // searchsorted(..., right=True)
+    idx = min(idx, PF_P - 1);
+#pragma unroll
+    for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
+    float pn = expf(vec[idx]);
+    pn = logf(pn / (al * pn + floor_));
+    const float mx2 = wave_max(act ? pn : -INFINITY);
+    const float lse = logf(wave_sum(act ? expf(pn - mx2) : 0.0f)) + mx2;
+    p1 = pn - lse;
+    if (a_.carry && (a_.mask == nullptr || a_.mask[n]) && act) {
+        float* hw = a_.h + (slot * PF_P + lane) * PF_H;
+#pragma unroll
+        for (int u = 0; u < PF_H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
+        a_.p[slot * PF_P + lane] = p1;
+    }
+    // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
+    __builtin_amdgcn_wave_barrier();
+    const float wgt = expf(p1);
+#pragma unroll
+    for (int u = 0; u < PF_H; ++u) if (act) tile[lane * PF_ROW + u] = wgt * h1[u];
+    __builtin_amdgcn_wave_barrier();
+    const int ul = lane < PF_H ? lane : PF_H - 1;
+    float mean = 0.0f;
+    for (int q = 0; q < PF_P; ++q) mean += tile[q * PF_ROW + ul];
+    __builtin_amdgcn_wave_barrier();
+    vec[lane] = mean;                                              // lanes 0..23: mean_hid[lane]
+    __builtin_amdgcn_wave_barrier();
+    const float* wg = a_.w + (size_t)own * PF_STRIDE;
+    float t = wg[PF_H0B + ul];
+    for (int k = 0; k < PF_H; ++k) t = fmaf(wg[PF_H0 + k * 24 + ul], vec[k], t);
+    t = fmaxf(t, 0.0f);
+    const float o0 = wave_sum(lane < PF_H ? wg[PF_H2 + ul] * t : 0.0f) + wg[PF_H2B];
+    const float o1 = wave_sum(lane < PF_H ? wg[PF_H2 + 24 + ul] * t : 0.0f) + wg[PF_H2B + 1];
+    if (lane == 0) {
+        float* out = a_.pred + ((size_t)n * a_.A + own) * 2;
+        out[0] = fmaxf(o0, 0.0f); out[1] = fmaxf(o1, 0.0f);
+    }
+}
+
+// reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: h0 ~ U[0,1) from the hash (kind 0), p0 = log(1 / P).
+// One lane per (owner, env, particle); the caller has already advanced episode[] and zeroed calls[] for those envs.
+__global__ void __launch_bounds__(256) rs_pfgru_reset_kernel(float* h, float* p, const int64_t* base, const int64_t* episode,
+                                                             const int64_t* calls, const uint8_t* mask, int N, int A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)A * N * PF_P) return;
+    const int pl = (int)(i % PF_P);
+    const long long slot = i / PF_P;
+    const int n = (int)(slot % N);
+    if (mask && !mask[n]) return;
+    const uint64_t kb = (uint64_t)base[slot] * 1000003ull;
+    const uint64_t ctr8 = ((uint64_t)episode[n] * 100003ull + (uint64_t)calls[n]) * 8ull;
+    const uint64_t pk = (kb ^ (ctr8 * 0xA24BAED4963EE407ull)) * 1048583ull + (uint64_t)pl * 4096ull;
+    float* hw = h + i * PF_H;
+#pragma unroll
+    for (int u = 0; u < PF_H; u += 4) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (float)((double)(pf_hash(pk + (uint64_t)(u + q)) >> 11) * (1.0 / 9007199254740992.0));
+        *reinterpret_cast<float4*>(hw + u) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    p[i] = -3.6888794541139363f;                                   // float32(log(1 / 40))
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
+                   int32_t num_envs, int32_t num_agents, rs_stream_t stream) {
+    if (!h || !p || !base_key || !episode || !calls || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
+    const long long lanes = (long long)num_envs * num_agents * PF_P;
+    hipLaunchKernelGGL(rs_pfgru_reset_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h, p, base_key, episode, calls, mask, num_envs, num_agents);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
+                  const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
+                  int32_t num_agents, rs_stream_t stream) {
+    if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || num_envs < 1 || num_agents < 1)
+        return RS_ERR_INVALID_ARG;
+    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, num_envs, num_agents, carry_hidden ? 1 : 0, (float)alpha,
+             (float)((1.0 - alpha) / (double)PF_P)};
+    const long long waves = (long long)num_envs * num_agents;
+    hipLaunchKernelGGL(rs_pfgru_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
+                       static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+}  // extern "C"

@@ -124,8 +124,14 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     const bool own = lane < 16;                                   // lane (j, 0) owns env slot j
     const int n = blockIdx.x * 16 + j;                            // N % 16 == 0 (checked by the host)
     const int N = P.N, T = R.steps_per_epoch, L = R.steps_per_episode;
+    // obstacles: the four lanes (j, 0..3) of an env run its step together (rs_env_step_lane<true, 4>): lane (j, g) takes
+    // corner g of every rectangle in the shortest-path loop, every 4th rectangle, two of the eight probe directions
+    const int cj = lane >> 4;
     RsGeo g{lds_geo, 0, 0, 0};
-    if (HAS_OBS) rs_load_geo(P, n, own, lds_geo, g);
+    if (HAS_OBS) {
+        rs_load_geo(P, n, own, lds_geo, g);
+        g.off = __shfl(g.off, j); g.stride = __shfl(g.stride, j); g.n = __shfl(g.n, j);
+    }
     __syncthreads();
 
     float oraw[RS_OBS_DIM];
@@ -149,11 +155,11 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     { float vv[1]; CRT.forward(xs, vv); v = vv[0]; }
 
     RsOut O;
-    O.obs_row = tile + lane * RS_OBS_DIM;
-    O.reward = lds_rew + lane - (size_t)n;
+    O.obs_row = tile + j * RS_OBS_DIM;
+    O.reward = lds_rew + j - (size_t)n;
     O.team = nullptr;
-    O.done = lds_done + lane - (size_t)n;
-    O.oob = lds_oob + lane - (size_t)n;
+    O.done = lds_done + j - (size_t)n;
+    O.oob = lds_oob + j - (size_t)n;
     O.oobc = nullptr; O.blocked = nullptr; O.collision = nullptr;
 
     for (int t = 0; t < T; ++t) {
@@ -201,7 +207,14 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
             R.val[row] = v;
             R.source_tar[row * 2 + 0] = (float)P.src_x[n];
             R.source_tar[row * 2 + 1] = (float)P.src_y[n];
-            rs_env_step_lane<HAS_OBS>(P, g, n, [&](int) -> int { return a; }, O);
+        }
+        if (HAS_OBS) {
+            const int a_env = __shfl(a, j);
+            rs_env_step_lane<true, 4>(P, g, n, [&](int) -> int { return a_env; }, O, false, cj);
+        } else if (own) {
+            rs_env_step_lane<false>(P, g, n, [&](int) -> int { return a; }, O);
+        }
+        if (own) {
             const float r = lds_rew[lane];
             const bool terminal = lds_done[lane] != 0;
             oob_count += lds_oob[lane];
@@ -231,10 +244,19 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
                 ep_ret_sq += (double)ep_ret * (double)ep_ret;
                 ep_ret_max = fmaxf(ep_ret_max, ep_ret); ep_ret_min = fminf(ep_ret_min, ep_ret);
             }
-            if (cut) {
+        }
+        if (HAS_OBS) {
+            if (__shfl((int)cut, j) != 0) {                      // the env's four lanes reset it together
                 if (ended) P.epoch_end[n] = 1;
+                rs_env_reset_lane<true, 4>(P, g, n, lds_geo, lds_adj, lds_d, tile + j * RS_OBS_DIM, O, j, cj);
+            }
+        } else if (cut) {
+            if (ended) P.epoch_end[n] = 1;
+            rs_env_reset_lane<false>(P, g, n, lds_geo, lds_adj, lds_d, tile + lane * RS_OBS_DIM, O);
+        }
+        if (own) {
+            if (cut) {
                 W.reset();
-                rs_env_reset_lane<HAS_OBS>(P, g, n, lds_geo, lds_adj, lds_d, tile + lane * RS_OBS_DIM, O);
 #pragma unroll
                 for (int k = 0; k < RS_OBS_DIM; ++k) oraw[k] = tile[lane * RS_OBS_DIM + k];
                 W.update((double)oraw[0]);

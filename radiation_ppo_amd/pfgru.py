@@ -19,12 +19,15 @@ and h0 from torch's global CPU generator.  Here they come from a counter-based h
 episode count, prediction count, particle, unit), so a rollout does not depend on how envs are sharded over GPUs.  The cell itself takes the draws
 as arguments: tests inject the reference's recorded draws and compare outputs (tests/golden/pfgru.npz).
 """
+import ctypes as C
 import math
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
 
 _M64 = (1 << 64) - 1
 
@@ -38,13 +41,53 @@ def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
     return torch.bitwise_right_shift(x, s) & ((1 << (64 - s)) - 1)
 
 
-def hash_uniform(key: torch.Tensor) -> torch.Tensor:
-    """int64 keys -> float64 uniforms in [0, 1): the splitmix64 finaliser (Steele et al. 2014) on wrapping int64 arithmetic."""
+def hash_bits(key: torch.Tensor) -> torch.Tensor:
+    """int64 keys -> 64 mixed bits: the splitmix64 finaliser (Steele et al. 2014) on wrapping int64 arithmetic
+    (csrc/rs_pfgru.hip: pf_hash is the same function)."""
     x = key * _s64(0x9E3779B97F4A7C15) + _s64(0xD1B54A32D192ED03)
     x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
     x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
-    x = x ^ _lsr(x, 31)
-    return _lsr(x, 11).double() * (1.0 / 9007199254740992.0)
+    return x ^ _lsr(x, 31)
+
+
+def hash_uniform(key: torch.Tensor) -> torch.Tensor:
+    """int64 keys -> float64 uniforms in [0, 1) from the top 53 bits."""
+    return _lsr(hash_bits(key), 11).double() * (1.0 / 9007199254740992.0)
+
+
+def hash_normal(key: torch.Tensor) -> torch.Tensor:
+    """int64 keys -> float32 standard normals: Box-Muller in float32 on two 24-bit uniforms cut from ONE hash
+    (bits 63..40 -> u1 in (0, 1], bits 39..16 -> u2 in [0, 1)); what the step kernel evaluates per (particle, unit)."""
+    x = hash_bits(key)
+    u1 = (_lsr(x, 40) + 1).float() * (1.0 / 16777216.0)
+    u2 = (_lsr(x, 16) & 0xFFFFFF).float() * (1.0 / 16777216.0)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.2831855 * u2)
+
+
+# packed per-owner weights of csrc/rs_pfgru.hip (floats): offsets of the blocks and the owner stride
+_PF_K = 27
+_PF_ZR, _PF_ZRB, _PF_N, _PF_NB, _PF_O, _PF_OB, _PF_H0, _PF_H0B, _PF_H2, _PF_H2B, PF_WEIGHT_FLOATS = (
+    0, 1296, 1344, 2640, 2688, 2715, 2720, 3296, 3320, 3368, 3376)
+
+
+def pack_weights(cells) -> torch.Tensor:
+    """[A, PF_WEIGHT_FLOATS] float32: zr_t [27][48] | zr_b | n_t [27][48] | n_b | o_w [27] | o_b | h0_t [24][24] | h0_b | h2_w [2][24] | h2_b."""
+    rows = []
+    for c in cells:
+        assert c.h_dim == 24 and c.num_particles == 40 and c.input_size == 3, "rs_pfgru_step is built for 40 particles x 24 units"
+        w = torch.zeros(PF_WEIGHT_FLOATS, dtype=torch.float32, device=c.fc_z.weight.device)
+        w[_PF_ZR:_PF_ZRB] = torch.cat([c.fc_z.weight, c.fc_r.weight], 0).t().reshape(-1)
+        w[_PF_ZRB:_PF_N] = torch.cat([c.fc_z.bias, c.fc_r.bias], 0)
+        w[_PF_N:_PF_NB] = c.fc_n.weight.t().reshape(-1)
+        w[_PF_NB:_PF_O] = c.fc_n.bias
+        w[_PF_O:_PF_OB] = c.fc_obs.weight.reshape(-1)
+        w[_PF_OB] = c.fc_obs.bias[0]
+        w[_PF_H0:_PF_H0B] = c.hid_obs[0].weight.t().reshape(-1)
+        w[_PF_H0B:_PF_H2] = c.hid_obs[0].bias
+        w[_PF_H2:_PF_H2B] = c.hid_obs[2].weight.reshape(-1)
+        w[_PF_H2B:_PF_H2B + 2] = c.hid_obs[2].bias
+        rows.append(w)
+    return torch.stack(rows).contiguous()
 
 
 class PFGRUCell(nn.Module):
@@ -107,8 +150,19 @@ class PredictorBank:
     """One PFGRUCell per owner, evaluated for all envs at once; what feeds heat-map channel 0 (`rs_maps_update`'s pred)."""
 
     def __init__(self, num_envs: int, number_agents: int, hidden_size: int = 24, seed: int = 0, env_id_base: int = 0,
-                 carry_hidden: bool = False, device="cuda:0"):
+                 carry_hidden: bool = False, device="cuda:0", impl: str = "hip"):
+        """impl: "hip" = the fused step / reset kernels (csrc/rs_pfgru.hip through the C ABI; the product path, cuda only);
+        "torch" = the same arithmetic composed from torch ops (what the kernel is tested against; also runs on the CPU)."""
+        assert impl in ("hip", "torch")
         self.N, self.A, self.dev = num_envs, number_agents, torch.device(device)
+        self.impl = impl
+        if impl == "hip":
+            if self.dev.type != "cuda":
+                raise RuntimeError("PredictorBank(impl='hip') needs a cuda device; there is no CPU fallback for the product path")
+            if hidden_size != 24:
+                raise NotImplementedError("rs_pfgru_step is built for the reference's 24 hidden units (RADTEAM_core.py:1790-1795)")
+            self._lib = _lib.load()
+            self._pred = torch.zeros(num_envs, number_agents, 2, dtype=torch.float32, device=self.dev)
         self.cells = [PFGRUCell(hidden_size=hidden_size).to(self.dev) for _ in range(number_agents)]
         self.carry_hidden = carry_hidden
         P, H = self.cells[0].num_particles, hidden_size
@@ -138,11 +192,29 @@ class PredictorBank:
         m1 = torch.ones(self.N, dtype=torch.bool, device=self.dev) if mask is None else mask.bool()
         self.episode = self.episode + m1.long()
         self.calls = torch.where(m1, torch.zeros_like(self.calls), self.calls)
+        if self.impl == "hip":
+            m8 = None if mask is None else m1.to(torch.uint8)
+            with _lib.timed("rs_pfgru_reset"):
+                _lib.check(self._lib.rs_pfgru_reset(self.h.data_ptr(), self.p.data_ptr(), self._base.data_ptr(), self.episode.data_ptr(),
+                                                    self.calls.data_ptr(), None if m8 is None else m8.data_ptr(), self.N, self.A,
+                                                    self._stream()), "rs_pfgru_reset")
+            return
         k = self._key(0)
         u = hash_uniform(k.view(self.A, self.N, 1, 1) * 1048583 + self._pu.view(1, 1, self.P, self.H)).float()
         m = m1.view(1, self.N, 1, 1)
         self.h = torch.where(m, u, self.h)
         self.p = torch.where(m.view(1, self.N, 1), torch.full_like(self.p, math.log(1.0 / self.P)), self.p)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _packed(self) -> torch.Tensor:
+        ver = tuple(p._version for c in self.cells for p in c.parameters())
+        if getattr(self, "_pack_ver", None) != ver:
+            with torch.no_grad():
+                self._wpack = pack_weights(self.cells)
+            self._pack_ver = ver
+        return self._wpack
 
     def _stacked(self):
         """The owners' weights stacked along a leading owner axis ([A, in, out] for bmm); rebuilt when a cell's parameters change
@@ -166,11 +238,20 @@ class PredictorBank:
         (scaled coordinates).  `mask`: the envs this round counts for (bootstrap rounds); the others' rows are to be discarded.
         All owners go through the same batched matrix products (PFGRUCell.forward's arithmetic, owner axis first)."""
         A, N, P, H = self.A, self.N, self.P, self.H
+        if self.impl == "hip":
+            assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (N, A, _lib.RS_OBS_DIM)
+            m8 = None if mask is None else mask.to(torch.uint8)
+            with _lib.timed("rs_pfgru_step"):
+                _lib.check(self._lib.rs_pfgru_step(self._packed().data_ptr(), obs.data_ptr(), self.h.data_ptr(), self.p.data_ptr(),
+                                                   self._base.data_ptr(), self.episode.data_ptr(), self.calls.data_ptr(),
+                                                   None if m8 is None else m8.data_ptr(), 1 if self.carry_hidden else 0,
+                                                   float(self.cells[0].resamp_alpha), self._pred.data_ptr(), N, A, self._stream()),
+                           "rs_pfgru_step")
+            self.calls = self.calls + (1 if mask is None else mask.long())
+            return self._pred.clone()
         W = self._stacked()
         k_eps, k_res = self._key(1), self._key(2)                                                           # [A, N]
-        key = k_eps.view(A, N, 1, 1) * 1048583 + self._pu.view(1, 1, P, H)
-        u1, u2 = hash_uniform(key), hash_uniform(key + 2048)
-        eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()              # Box-Muller [A, N, P, H]
+        eps = hash_normal(k_eps.view(A, N, 1, 1) * 1048583 + self._pu.view(1, 1, P, H))                     # [A, N, P, H]
         ru = hash_uniform(k_res.view(A, N, 1) * 1048583 + self._pu[:, 0].view(1, 1, P))                     # [A, N, P]
         h0, p0 = self.h, self.p
         x = obs[:, :, :3].permute(1, 0, 2).unsqueeze(2).expand(A, N, P, 3)                                  # owner a feeds its own row

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from scipy import stats
 
-from radiation_ppo_amd.pfgru import PFGRUCell, PredictorBank, hash_uniform
+from radiation_ppo_amd.pfgru import PFGRUCell, PredictorBank, hash_normal, hash_uniform
 
 
 def _cell(g):
@@ -99,8 +99,8 @@ def test_hash_uniform_statistics():
 def test_predictor_bank_is_sharding_invariant_and_deterministic():
     """Draws are keyed by the GLOBAL env id: envs 8..15 of a 16-env bank equal the 8 envs of a bank with env_id_base = 8."""
     torch.manual_seed(0)
-    full = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu")
-    half = PredictorBank(8, 2, seed=5, env_id_base=8, device="cpu")
+    full = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu", impl="torch")
+    half = PredictorBank(8, 2, seed=5, env_id_base=8, device="cpu", impl="torch")
     for a in range(2):
         half.load_state_dict(a, full.state_dict(a))
     rng = np.random.default_rng(1)
@@ -115,17 +115,17 @@ def test_predictor_bank_is_sharding_invariant_and_deterministic():
             m = torch.arange(16) % 3 == 0
             full.reset(m); half.reset(m[8:])
             assert torch.equal(full.h[:, 8:], half.h)
-    again = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu")
+    again = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu", impl="torch")
     for a in range(2):
         again.load_state_dict(a, full.state_dict(a))
     again.reset()
     first = again.predict(obs)
-    other = PredictorBank(16, 2, seed=6, env_id_base=0, device="cpu")
+    other = PredictorBank(16, 2, seed=6, env_id_base=0, device="cpu", impl="torch")
     for a in range(2):
         other.load_state_dict(a, full.state_dict(a))
     other.reset()
     assert not torch.equal(first, other.predict(obs))                # a different seed gives different draws
-    again2 = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu")
+    again2 = PredictorBank(16, 2, seed=5, env_id_base=0, device="cpu", impl="torch")
     for a in range(2):
         again2.load_state_dict(a, full.state_dict(a))
     again2.reset()
@@ -137,7 +137,7 @@ def test_bank_batched_over_owners_equals_the_cell():
     (the function pinned to the reference above) on the same draws."""
     import math
     torch.manual_seed(3)
-    bank = PredictorBank(6, 3, seed=11, env_id_base=40, device="cpu")
+    bank = PredictorBank(6, 3, seed=11, env_id_base=40, device="cpu", impl="torch")
     rng = np.random.default_rng(2)
     obs = torch.from_numpy(rng.uniform(0, 1.5, (6, 3, 11)).astype(np.float32))
     bank.reset()
@@ -145,9 +145,7 @@ def test_bank_batched_over_owners_equals_the_cell():
     k_eps, k_res = bank._key(1), bank._key(2)
     got = bank.predict(obs)
     for a in range(3):
-        key = k_eps[a].view(6, 1, 1) * 1048583 + bank._pu.view(1, 40, 24)
-        u1, u2 = hash_uniform(key), hash_uniform(key + 2048)
-        eps = (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).float()
+        eps = hash_normal(k_eps[a].view(6, 1, 1) * 1048583 + bank._pu.view(1, 40, 24))
         ru = hash_uniform(k_res[a].view(6, 1) * 1048583 + bank._pu[:, 0].view(1, 40))
         with torch.no_grad():
             want, _ = bank.cells[a](obs[:, a, :3].contiguous(), (h0[a], p0[a]), eps, resample_u=ru)
