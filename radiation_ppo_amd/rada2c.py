@@ -1,0 +1,538 @@
+"""RAD-A2C: the recurrent actor-critic with its PFGRU source-location module, batched over envs.
+
+Mirrors (paths relative to the reference root):
+  RNNModelActorCritic <- algos/multiagent/NeuralNetworkCores/RADA2C_core.py:477-607 as main.py:541-553 instantiates it:
+                         GRU(11 + 2 -> 24) whose hidden state feeds two heads, Woms = Linear(24, 32)-Tanh-Linear(32, 8) (logits)
+                         and Valms = Linear(24, 32)-Tanh-Linear(32, 1) (value) (SeqPt :351-391), plus model = PFGRUCell(40
+                         particles, 3 inputs, 24 units, alpha 0.7, tanh) (:215-307) whose location prediction is appended to the
+                         11 observations (step :528-548, grad_step :550-566).  Same module / parameter names, so state_dicts
+                         (pyt_save/model.pt) interchange.
+  RNNAgentPPO         <- AgentPPO with actor_critic_architecture="rnn" (algos/multiagent/ppo.py:644-666): update_agent (:746-813)
+                         = update_model (:1047-1148: PFGRU regression + ELBO loss, back-propagated through the episode, gradient
+                         clipped to norm 5) once, then up to train_pi_iters x update_rada2c (:1150-1281: per-episode PPO-clip /
+                         value / detached-entropy loss, BPTT through the GRU, KL early stop), then both StepLR schedulers.
+  RNNCollector        <- the 'rnn' branches of train_PPO.train (algos/multiagent/train.py:300-548): hidden states reset at every
+                         epoch start and episode end (:322-329, :505-518), carried through ac.step (:345-351), bootstrap values
+                         from one extra step (:462-487).
+
+What is batched: the reference holds one env per MPI rank and loops over that rank's episodes; here an epoch's [T, N] buffer is
+re-packed EPISODE-major ([L <= 120 steps, E episodes]) so that the time loop is 120 steps long whatever N is, and the
+reference's "mean over ranks of the mean over the rank's episodes of the per-episode mean" becomes per-sample weights.
+The per-step PFGRU forward of the collector is K11 (csrc/rs_pfgru.hip) with carried particle sets; the GRU / head arithmetic
+and the two updates are torch (autograd supplies BPTT).  Random draws (initial hidden states, reparameterisation noise,
+resampling) come from counter hashes keyed by global env id / episode / epoch (the documented RNG deviation of pfgru.py);
+tests inject the reference's recorded draws instead (tests/golden/rada2c_core.npz).
+
+Deviations, all forced by batching and stated here: (i) update_model clips the gradient AFTER the average over envs (the
+reference clips per rank, then averages, ppo.py:1137-1141); (ii) LocLoss is the RMS over all samples (the reference reports the
+loop's last episode, :1274); (iii) several agents are independent copies, each fed its own observation row.
+"""
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .envs import RadSearchVec
+from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
+from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
+
+
+class _SeqPt(nn.Module):
+    """SeqPt (RADA2C_core.py:351-391)."""
+
+    def __init__(self, input_size: int, hid: int, pol: int, val: int, act_dim: int):
+        super().__init__()
+        self.seq_model = nn.GRU(input_size, hid, 1)
+        self.Woms = nn.Sequential(nn.Linear(hid, pol), nn.Tanh(), nn.Linear(pol, act_dim))     # mlp(...)[:-1] (:363-366)
+        self.Valms = nn.Sequential(nn.Linear(hid, val), nn.Tanh(), nn.Linear(val, 1))         # (:367-368)
+
+
+class _RecurrentNet(nn.Module):
+    def __init__(self, *a):
+        super().__init__()
+        self.v_net = _SeqPt(*a)
+
+
+class _Actor(nn.Module):
+    def __init__(self, *a):
+        super().__init__()
+        self.logits_net = _RecurrentNet(*a)
+
+
+class RNNModelActorCritic(nn.Module):
+    def __init__(self, obs_dim: int = 11, act_dim: int = 8, hidden=((24,),), hidden_sizes_pol=((32,),), hidden_sizes_val=((32,),),
+                 hidden_sizes_rec=(24,), pad_dim: int = 2, net_type: str = "rnn", seed: int = 0, **unused: Any):
+        super().__init__()
+        hid, pol, val = int(hidden[0][0]), int(hidden_sizes_pol[0][0]), int(hidden_sizes_val[0][0])
+        if len(hidden_sizes_pol) != 1 or len(hidden_sizes_val) != 1:
+            raise NotImplementedError("one hidden layer per head (the reference's defaults l_pol = l_val = 1, main.py:131-134)")
+        self.hid, self.obs_dim, self.act_dim = hid, obs_dim, act_dim
+        self.pi = _Actor(obs_dim + pad_dim, hid, pol, val, act_dim)
+        self.model = PFGRUCell(input_size=obs_dim - 8, obs_size=obs_dim - 8, hidden_size=int(hidden_sizes_rec[0]))
+        self.num_particles, self.alpha = 40, 0.7
+
+    # ---- batched arithmetic
+    def gru_cell(self, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+        """One nn.GRU step (gate order r, z, n): x [B, 13], h [B, hid]."""
+        g = self.pi.logits_net.v_net.seq_model
+        gi = F.linear(x, g.weight_ih_l0, g.bias_ih_l0)
+        gh = F.linear(h, g.weight_hh_l0, g.bias_hh_l0)
+        H = self.hid
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        return (1.0 - z) * n + z * h
+
+    def heads(self, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        v = self.pi.logits_net.v_net
+        return v.Woms(h), v.Valms(h).squeeze(-1)
+
+    def policy_step(self, obs: torch.Tensor, loc_pred: torch.Tensor, h: torch.Tensor):
+        """step (:528-548) after the PFGRU: logits [B, 8], value [B], new GRU state [B, hid]."""
+        h1 = self.gru_cell(torch.cat((obs, loc_pred), dim=1), h)
+        logits, val = self.heads(h1)
+        return logits, val, h1
+
+    def gru_h0(self, u: torch.Tensor) -> torch.Tensor:
+        """_get_init_states (:458-461): U(-1/sqrt(hid), 1/sqrt(hid)) from uniforms u in [0, 1)."""
+        std = 1.0 / math.sqrt(self.hid)
+        return (u.float() * 2.0 - 1.0) * std
+
+
+# ------------------------------------------------------------------------------------------------ draws
+class HashDraws:
+    """Counter-hash draws of one pass over an episode batch: keys [E] int64 identify (seed, global env, episode, epoch, pass)."""
+
+    def __init__(self, keys: torch.Tensor, P: int = 40, H: int = 24, hid: int = 24):
+        self.k = keys
+        dev = keys.device
+        self._pu = (torch.arange(P, dtype=torch.int64, device=dev).view(P, 1) * 4096 + torch.arange(H, dtype=torch.int64, device=dev).view(1, H))
+        self._g = torch.arange(hid, dtype=torch.int64, device=dev)
+
+    def _key(self, kind: int, t: int = 0) -> torch.Tensor:
+        return (self.k * 1000003) ^ _s64((t * 8 + kind) * 0xA24BAED4963EE407)
+
+    def pf_h0(self) -> torch.Tensor:
+        return hash_uniform(self._key(0).view(-1, 1, 1) * 1048583 + self._pu.unsqueeze(0)).float()
+
+    def gru_h0_u(self) -> torch.Tensor:
+        return hash_uniform(self._key(3).view(-1, 1) * 1048583 + self._g.unsqueeze(0))
+
+    def eps(self, t: int) -> torch.Tensor:
+        return hash_normal(self._key(1, t).view(-1, 1, 1) * 1048583 + self._pu.unsqueeze(0))
+
+    def resample(self, t: int) -> Dict[str, torch.Tensor]:
+        return dict(resample_u=hash_uniform(self._key(2, t).view(-1, 1) * 1048583 + self._pu[:, 0].unsqueeze(0)))
+
+
+class RecordedDraws:
+    """The reference's own draws (tests): pf_h0 [E, P, H], gru_h0 [E, hid], eps [L, E, P, H], idx [L, E, P]."""
+
+    def __init__(self, pf_h0, gru_h0, eps, idx):
+        self._pf, self._g, self._eps, self._idx = pf_h0, gru_h0, eps, idx
+
+    def pf_h0(self):
+        return self._pf
+
+    def gru_h0(self):
+        return self._g
+
+    def eps(self, t):
+        return self._eps[t]
+
+    def resample(self, t):
+        return dict(resample_idx=self._idx[t])
+
+
+# ------------------------------------------------------------------------------------------------ episode-major batch
+@dataclass
+class EpisodeBatch:
+    """An epoch's samples, episode-major.  L = longest episode, E = episodes (the trailing partial one of every env included,
+    PPOBuffer.get :480-487).  Padded steps carry weight 0."""
+    X: torch.Tensor          # [L, E, 11] standardised observations
+    act: torch.Tensor        # [L, E] int64
+    adv: torch.Tensor        # [L, E]
+    ret: torch.Tensor        # [L, E]
+    logp: torch.Tensor       # [L, E]
+    src: torch.Tensor        # [L, E, 2] source coordinates (cm)
+    valid: torch.Tensor      # [L, E] bool
+    lens: torch.Tensor       # [E] int64
+    w_ep: torch.Tensor       # [E] 1 / (global env count x episodes of the env): the weight of an episode's loss
+    key: torch.Tensor        # [E] int64 draw keys
+
+    @property
+    def w(self) -> torch.Tensor:
+        """per-sample weights: w_ep / len on valid steps."""
+        return (self.w_ep / self.lens.float()).unsqueeze(0) * self.valid.float()
+
+
+def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base: int = 0, seed: int = 0, epoch: int = 0) -> EpisodeBatch:
+    """[T, N, ...] time-major columns -> EpisodeBatch.  cut [T, N] closes an episode (terminal, timeout or epoch end)."""
+    T, N = cut.shape
+    dev = cut.device
+    c = cut.long()
+    start = torch.ones(T, N, dtype=torch.int64, device=dev)
+    start[1:] = c[:-1]
+    k_in_env = torch.cumsum(start, dim=0) - 1                               # episode index inside the env's column
+    n_ep = k_in_env[-1] + 1                                                  # [N]
+    off = torch.cumsum(n_ep, dim=0) - n_ep
+    eid = k_in_env + off.unsqueeze(0)                                        # [T, N] global episode index
+    tt = torch.arange(T, device=dev).unsqueeze(1).expand(T, N)
+    t0 = torch.cummax(torch.where(start.bool(), tt, torch.zeros_like(tt)), dim=0).values
+    pos = tt - t0
+    E = int(n_ep.sum().item())
+    L = int(pos.max().item()) + 1
+    flat = (pos * E + eid).reshape(-1)
+
+    def scat(x, fill=0.0):
+        tail = x.shape[2:]
+        out = torch.full((L * E,) + tuple(tail), fill, dtype=x.dtype, device=dev)
+        out[flat] = x.reshape((T * N,) + tuple(tail))
+        return out.view((L, E) + tuple(tail))
+    lens = torch.zeros(E, dtype=torch.int64, device=dev)
+    lens.scatter_add_(0, eid.reshape(-1), torch.ones(T * N, dtype=torch.int64, device=dev))
+    valid = torch.arange(L, device=dev).unsqueeze(1) < lens.unsqueeze(0)
+    env_of = torch.repeat_interleave(torch.arange(N, device=dev), n_ep)
+    w_ep = 1.0 / (float(n_total) * n_ep[env_of].float())
+    k_of = torch.arange(E, device=dev) - off[env_of]
+    key = hash_uniform(((env_of + int(env_id_base)) * 4096 + k_of) ^ _s64((int(seed) * 0x2545F4914F6CDD1D) ^ (int(epoch) * 0x9E3779B97F4A7C15))).mul(2.0 ** 52).long()
+    return EpisodeBatch(X=scat(obs), act=scat(act), adv=scat(adv), ret=scat(ret), logp=scat(logp), src=scat(src), valid=valid,
+                        lens=lens, w_ep=w_ep, key=key)
+
+
+# ------------------------------------------------------------------------------------------------ agent
+@dataclass
+class BpArgs:
+    """ppo.py:160-167."""
+    bp_decay: float = 0.1
+    l2_weight: float = 1.0
+    l1_weight: float = 0.0
+    elbo_weight: float = 1.0
+    area_scale: float = 2500.0
+
+
+class RNNAgentPPO:
+    def __init__(self, id: int, observation_space: int = 11, action_space: int = 8, steps_per_epoch: int = 480,
+                 steps_per_episode: int = 120, number_of_agents: int = 1, actor_critic_architecture: str = "rnn",
+                 actor_critic_args: Optional[Dict[str, Any]] = None, train_pi_iters: int = 40, train_pfgru_iters: int = 15,
+                 actor_learning_rate: float = 3e-4, pfgru_learning_rate: float = 5e-3, gamma: float = 0.99, alpha: float = 0.1,
+                 clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, bp_args: Optional[Any] = None,
+                 env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 4096,
+                 GlobalCriticOptimizer=None, **unused: Any):
+        if actor_critic_architecture != "rnn":
+            raise ValueError("Unsupported Neural Network type requested")
+        if GlobalCriticOptimizer is not None:
+            raise Exception("No global critic option for RAD-A2C")             # ppo.py:651-652
+        self.id, self.device = id, torch.device(device)
+        self.gamma, self.lam, self.alpha, self.clip_ratio, self.target_kl = gamma, lam, alpha, clip_ratio, target_kl
+        self.train_pi_iters, self.train_pfgru_iters = train_pi_iters, train_pfgru_iters
+        self.reduce_pfgru_iters = True
+        b = bp_args if bp_args is not None else BpArgs(area_scale=env_height)
+        self.bp_args = BpArgs(*(b if isinstance(b, tuple) else (b.bp_decay, b.l2_weight, b.l1_weight, b.elbo_weight, b.area_scale)))
+        self.env_height, self.seed, self.episode_chunk = float(env_height), int(seed), int(episode_chunk)
+        args = dict(actor_critic_args or {})
+        args.setdefault("obs_dim", observation_space); args.setdefault("act_dim", action_space)
+        self.agent = RNNModelActorCritic(**args).to(self.device)
+        self.pi_optimizer = torch.optim.Adam(self.agent.pi.parameters(), lr=actor_learning_rate)
+        self.model_optimizer = torch.optim.Adam(self.agent.model.parameters(), lr=pfgru_learning_rate)
+        self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)        # ppo.py:205-210
+        self.pfgru_scheduler = torch.optim.lr_scheduler.StepLR(self.model_optimizer, step_size=100, gamma=0.99)
+        self.epochs_done = 0
+        self.agent.eval()
+
+    def reduce_pfgru_training(self) -> None:
+        """ppo.py:685-689."""
+        if self.reduce_pfgru_iters:
+            self.train_pfgru_iters = 5
+            self.reduce_pfgru_iters = False
+
+    def sync_params(self) -> None:
+        if _world() > 1:
+            for p in self.agent.parameters():
+                dist.broadcast(p.data, src=0)
+
+    def _allreduce(self, params) -> None:
+        if _world() == 1:
+            return
+        ps = [p for p in params if p.grad is not None]
+        flat = torch.cat([p.grad.view(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for p in ps:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p)); o += p.numel()
+
+    # ---- PFGRU over an episode chunk; returns loc [L, E, 2] and (optionally) per-particle predictions [L, E, P, 2]
+    def _pfgru_pass(self, X3: torch.Tensor, draws, want_particles: bool):
+        cell = self.agent.model
+        L, E = X3.shape[0], X3.shape[1]
+        h = draws.pf_h0()
+        p = torch.full((E, cell.num_particles), math.log(1.0 / cell.num_particles), dtype=torch.float32, device=X3.device)
+        locs, parts = [], []
+        for t in range(L):
+            loc, (h, p) = cell(X3[t], (h, p), draws.eps(t), **draws.resample(t))
+            locs.append(loc)
+            if want_particles:
+                parts.append(cell.hid_obs(h))                                     # particle_pred[zz] (ppo.py:1079)
+        return torch.stack(locs), (torch.stack(parts) if want_particles else None)
+
+    def model_loss(self, B: EpisodeBatch, sl: slice, draws) -> torch.Tensor:
+        """Sum over the chunk's episodes of w_ep x total_loss (ppo.py:1062-1128)."""
+        a = self.bp_args
+        X3, valid, lens = B.X[:, sl, :3], B.valid[:, sl], B.lens[sl]
+        L = X3.shape[0]
+        tar = B.src[:, sl] / a.area_scale                                          # :1067 (padded rows: weight 0)
+        loc, part = self._pfgru_pass(X3, draws, True)
+        tt = torch.arange(L, device=X3.device, dtype=torch.float64).unsqueeze(1)
+        bp = torch.exp(a.bp_decay * tt) * valid.double()
+        bp = (bp / bp.sum(dim=0, keepdim=True)).float()                            # :1074-1075 (numpy float64, then FloatTensor)
+        bp3 = bp.unsqueeze(-1)
+        l2_loss = ((loc - tar) ** 2 * bp3).sum(dim=(0, 2))                          # torch.sum over the episode (:1093)
+        n_el = (lens * 2).float()
+        l1_loss = 10.0 * ((loc - tar).abs() * bp3).sum(dim=(0, 2)) / n_el
+        pred_loss = a.l2_weight * l2_loss + a.l1_weight * l1_loss
+        tp = tar.unsqueeze(2)
+        bp4 = bp3.unsqueeze(2)
+        v4 = valid.float().unsqueeze(-1)
+        y2 = torch.exp(-((part - tp) ** 2) * bp4).mean(dim=2)                       # mean over particles (:1117-1119)
+        l2p = (-(y2.log()) * v4).sum(dim=(0, 2)) / n_el
+        y1 = torch.exp(-((part - tp).abs()) * bp4).mean(dim=2)
+        l1p = 10.0 * (-(y1.log()) * v4).sum(dim=(0, 2)) / n_el
+        total = pred_loss + a.elbo_weight * (a.l2_weight * l2p + a.l1_weight * l1p)
+        return (B.w_ep[sl] * total).sum()
+
+    def update_model(self, B: EpisodeBatch, draws_for=None) -> float:
+        """update_model (ppo.py:1047-1148).  draws_for(iteration, slice) -> draws; default: counter hashes."""
+        cell = self.agent.model
+        cell.train()
+        E = B.lens.shape[0]
+        last = 0.0
+        for it in range(self.train_pfgru_iters):
+            self.model_optimizer.zero_grad(set_to_none=True)
+            tot = torch.zeros((), dtype=torch.float64, device=self.device)
+            for lo in range(0, E, self.episode_chunk):
+                sl = slice(lo, min(lo + self.episode_chunk, E))
+                d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 1 + it)
+                loss = self.model_loss(B, sl, d)
+                loss.backward()
+                tot += loss.detach().double()
+            if _world() > 1:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            self._allreduce(cell.parameters())
+            torch.nn.utils.clip_grad_norm_(cell.parameters(), 5)                    # :1137 (after the average here, see header)
+            self.model_optimizer.step()
+            last = float(tot.item())
+        cell.eval()
+        return last
+
+    def a2c_losses(self, B: EpisodeBatch, sl: slice, draws):
+        """grad_step (:550-566) + the per-episode loss of update_rada2c (ppo.py:1191-1234) for an episode chunk.
+        Returns (loss to back-propagate, stats [kl, ent, clipfrac, val_loss, loss, sum w (h loc - src)^2, sum w])."""
+        ac = self.agent
+        X, valid = B.X[:, sl], B.valid[:, sl]
+        w = B.w[:, sl]
+        L, E = X.shape[0], X.shape[1]
+        with torch.no_grad():
+            loc, _ = self._pfgru_pass(X[..., :3], draws, False)
+        h = draws.gru_h0() if hasattr(draws, "gru_h0") else ac.gru_h0(draws.gru_h0_u())
+        lg, vs = [], []
+        for t in range(L):
+            logits, val, h = ac.policy_step(X[t], loc[t], h)
+            lg.append(logits); vs.append(val)
+        logp_all = torch.log_softmax(torch.stack(lg), dim=-1)                      # Categorical(logits=...) (:443-446)
+        val = torch.stack(vs)
+        logp = logp_all.gather(-1, B.act[:, sl].unsqueeze(-1)).squeeze(-1)
+        adv, ret, logp_old = B.adv[:, sl], B.ret[:, sl], B.logp[:, sl]
+        ratio = torch.exp(logp - logp_old)
+        clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv
+        surr = (w * torch.min(ratio * adv, clip_adv)).sum()
+        val_loss = (w * (val - ret) ** 2).sum()
+        with torch.no_grad():
+            ent = (w * -(logp_all.exp() * logp_all).sum(-1)).sum()
+            clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
+            kl = (w * (logp_old - logp)).sum()
+            cf = (w * clipped.float()).sum()
+            d2 = (w.unsqueeze(-1) * (self.env_height * loc - B.src[:, sl]) ** 2).sum() / 2.0
+        loss = -(surr - 0.01 * val_loss + self.alpha * ent)                         # entropy: a detached float in the reference (:1216)
+        stats = torch.stack([kl, ent, cf, val_loss.detach(), loss.detach(), d2, w.sum()]).double()
+        return loss, stats
+
+    def update_rada2c(self, B: EpisodeBatch, it: int = 0, draws_for=None):
+        """One call of update_rada2c: returns (stats list, terminated)."""
+        E = B.lens.shape[0]
+        self.pi_optimizer.zero_grad(set_to_none=True)
+        stats = torch.zeros(7, dtype=torch.float64, device=self.device)
+        for lo in range(0, E, self.episode_chunk):
+            sl = slice(lo, min(lo + self.episode_chunk, E))
+            d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 17 + it)
+            loss, st = self.a2c_losses(B, sl, d)
+            loss.backward()
+            stats += st
+        if _world() > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)                            # mpi_avg(kl) (:1250)
+        s = stats.tolist()
+        if s[0] < 1.5 * self.target_kl:
+            self._allreduce(self.agent.pi.parameters())
+            self.pi_optimizer.step()
+            return s, False
+        return s, True
+
+    def update_agent(self, B: EpisodeBatch) -> UpdateResult:
+        """update_agent, 'rnn' branch (ppo.py:776-811)."""
+        self.agent.train()
+        model_loss = self.update_model(B)
+        self.pi_optimizer.zero_grad(set_to_none=True)
+        kk, term, s = 0, False, None
+        while not term and kk < self.train_pi_iters:
+            s, term = self.update_rada2c(B, kk)
+            kk += 1
+        self.pi_scheduler.step(); self.pfgru_scheduler.step()
+        self.agent.eval()
+        self.epochs_done += 1
+        return UpdateResult(stop_iteration=kk, loss_policy=s[4], loss_critic=s[3], loss_predictor=model_loss, kl_divergence=s[0],
+                            Entropy=s[1], ClipFrac=s[2], LocLoss=math.sqrt(max(s[5], 0.0) / max(s[6], 1e-30)))
+
+    # ---- checkpoints: the reference saves the whole module with setup_pytorch_saver (train.py:220-223)
+    def save(self, path: str) -> None:
+        import os
+        os.makedirs(os.path.join(path, "pyt_save"), exist_ok=True)
+        torch.save(self.agent.state_dict(), os.path.join(path, "pyt_save", "model.pt"))
+
+    def load(self, path: str) -> None:
+        import os
+        self.agent.load_state_dict(torch.load(os.path.join(path, "pyt_save", "model.pt"), map_location=self.device))
+
+    def resume_state(self) -> Dict[str, Any]:
+        return dict(agent=self.agent.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(), model_optimizer=self.model_optimizer.state_dict(),
+                    pi_scheduler=self.pi_scheduler.state_dict(), pfgru_scheduler=self.pfgru_scheduler.state_dict(),
+                    epochs_done=self.epochs_done, train_pfgru_iters=self.train_pfgru_iters, reduce_pfgru_iters=self.reduce_pfgru_iters)
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        self.agent.load_state_dict(st["agent"])
+        self.pi_optimizer.load_state_dict(st["pi_optimizer"]); self.model_optimizer.load_state_dict(st["model_optimizer"])
+        self.pi_scheduler.load_state_dict(st["pi_scheduler"]); self.pfgru_scheduler.load_state_dict(st["pfgru_scheduler"])
+        self.epochs_done, self.train_pfgru_iters, self.reduce_pfgru_iters = st["epochs_done"], st["train_pfgru_iters"], st["reduce_pfgru_iters"]
+
+
+# ------------------------------------------------------------------------------------------------ collector
+class RNNCollector:
+    """The 'rnn' epoch loop of train_PPO.train for N envs at once (see the module docstring)."""
+
+    def __init__(self, env: RadSearchVec, agents: Dict[int, RNNAgentPPO], steps_per_epoch: int, steps_per_episode: int,
+                 global_critic_flag: bool = False):
+        if global_critic_flag:
+            raise Exception("No global critic option for RAD-A2C")
+        self.env, self.agents = env, agents
+        self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, env.number_agents
+        dev = env.device
+        hid = agents[0].agent.hid
+        self.buf = RolloutBuffer(self.T, self.N, self.A, _lib.RS_OBS_DIM, dev)
+        self.stat = DeviceWelford((self.N, self.A), dev)
+        self.steps_in_ep = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        self.ep_ret = torch.zeros(self.N, self.A, dtype=torch.float32, device=dev)
+        self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
+        self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
+        self.h = torch.zeros(self.A, self.N, hid, dtype=torch.float32, device=dev)                 # GRU states
+        self.bank = PredictorBank(self.N, self.A, hidden_size=24, seed=int(env.cfg.seed), env_id_base=int(env.cfg.env_id_base),
+                                  carry_hidden=True, device=dev)
+        for a, ag in agents.items():                                         # the bank evaluates the agents' own PFGRU modules
+            self.bank.cells[a] = ag.agent.model
+        self.episodes_begun = torch.zeros(self.N, dtype=torch.int64, device=dev)
+        self._gidx = torch.arange(hid, dtype=torch.int64, device=dev)
+        self.obs = None
+        self.started = False
+        self.epoch = 0
+
+    def _x(self, obs: torch.Tensor) -> torch.Tensor:
+        x = obs.clone()
+        x[..., 0] = self.stat.standardize(obs[..., 0])
+        return x
+
+    def _reset_hidden(self, mask: Optional[torch.Tensor]) -> None:
+        """reset_hidden (:583-586) for the masked envs: fresh particle sets (K11's reset kernel) and GRU h0 ~ U(-1/sqrt(hid), .)."""
+        self.bank.reset(mask)
+        m = torch.ones(self.N, dtype=torch.bool, device=self.h.device) if mask is None else mask.bool()
+        self.episodes_begun = self.episodes_begun + m.long()
+        key = (self.bank._base * 1000003) ^ ((self.episodes_begun.view(1, -1) * 8 + 5) * _s64(0xA24BAED4963EE407))      # [A, N]
+        u = hash_uniform(key.unsqueeze(-1) * 1048583 + self._gidx.view(1, 1, -1))
+        h0 = self.agents[0].agent.gru_h0(u)
+        self.h = torch.where(m.view(1, -1, 1), h0, self.h)
+
+    def start(self) -> None:
+        obs, *_ = self.env.reset()
+        self.obs = obs.clone()
+        self.stat.update(self.obs[..., 0])
+        self.started = True
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        if not self.started:
+            self.start()
+        env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
+        acc = EpochStats(A, env.device)
+        self._reset_hidden(None)                                                  # train.py:322-329: every epoch starts fresh
+        for t in range(T):
+            x = self._x(self.obs)                                                 # train.py:334-341
+            env.action_uniforms(self._u)
+            loc = self.bank.predict(x)                                            # PFGRU (K11), carried particle sets
+            for a, ag in self.agents.items():
+                logits, v, self.h[a] = ag.agent.policy_step(x[:, a], loc[:, a], self.h[a])
+                logp_all = torch.log_softmax(logits, dim=-1)
+                cdf = torch.cumsum(logp_all.exp(), dim=-1)
+                act = (cdf[:, :-1] <= self._u[:, a].unsqueeze(-1)).sum(dim=-1)    # inverse CDF on the env's Philox uniform (FF_core.py:101-104)
+                buf.act[t, :, a] = act
+                buf.logp[t, :, a] = logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+                buf.val[t, :, a] = v
+                self._act8[:, a] = act.to(torch.int8)
+            buf.obs[t] = x
+            buf.source_tar[t, :, 0] = env.state("src_x")[0].float()
+            buf.source_tar[t, :, 1] = env.state("src_y")[0].float()
+            next_obs, rew, team, done, info = env.step(self._act8)
+            buf.rew[t] = rew
+            self.ep_ret += rew
+            self.steps_in_ep += 1
+            terminal = done.bool().any(dim=1)
+            acc.step(info["out_of_bounds"], done)
+            timeout = self.steps_in_ep == L
+            episode_over = terminal | timeout
+            epoch_ended = t == T - 1
+            cut = episode_over | epoch_ended
+            buf.cut[t] = cut.unsqueeze(1).to(torch.uint8).expand(N, A)
+            self.stat.update(next_obs[..., 0])
+            self.obs = next_obs.clone()
+            boot = (timeout | epoch_ended) & cut                                  # train.py:462-487: one more ac.step for the value
+            xb = self._x(self.obs)
+            locb = self.bank.predict(xb, mask=boot)
+            for a, ag in self.agents.items():
+                _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
+                buf.last_val[t, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
+            acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
+            if epoch_ended:
+                env.set_epoch_end()
+            self.stat.reset(cut)
+            obs_r, *_ = env.reset(cut)
+            self.obs = obs_r.clone()
+            self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
+            self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
+            self.stat.update(self.obs[..., 0], mask=cut)
+            if not epoch_ended:
+                self._reset_hidden(cut)                                           # train.py:505-518
+        buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return acc.result()
+
+    def update(self) -> Dict[int, UpdateResult]:
+        buf = self.buf
+        out = {}
+        cut = buf.cut[:, :, 0]
+        for a, ag in self.agents.items():
+            adv = normalize_advantages(buf.adv[:, :, a])
+            B = pack_episodes(buf.obs[:, :, a], buf.act[:, :, a], adv, buf.ret[:, :, a], buf.logp[:, :, a], buf.source_tar, cut,
+                              n_total=self.N * _world(), env_id_base=int(self.env.cfg.env_id_base), seed=int(self.env.cfg.seed) + 7919 * a,
+                              epoch=self.epoch)
+            out[a] = ag.update_agent(B)
+        self.epoch += 1
+        return out

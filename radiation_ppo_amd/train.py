@@ -28,6 +28,7 @@ from .logger import EpochLogger, convert_json, setup_logger_kwargs
 from .maps import CNNCritic
 from .ppo import Collector, FusedCollector, VecAgentPPO
 from .ppo_cnn import CNNAgentPPO, CNNCollector
+from .rada2c import RNNAgentPPO, RNNCollector
 
 # progress.txt columns of the reference (train.py:605-627, epoch_logger.py:393-398) + throughput columns of this build
 COLUMNS = ["AgentID", "Epoch", "MeanVVals", "StdVVals", "MaxVVals", "MinVVals", "TotalEnvInteracts", "loss_policy",
@@ -90,10 +91,8 @@ class train_PPO:
     def __post_init__(self) -> None:
         if self.actor_critic_architecture != "cnn" and self.global_critic_flag:
             raise ValueError("Global critic not supported in RAD-A2C")        # train.py:157-160
-        if self.actor_critic_architecture not in ("ff", "mlp", "cnn"):
-            raise NotImplementedError(f"architecture {self.actor_critic_architecture!r}: the 2x64 MLP path ('ff', alias "
-                                      "'mlp') and the RAD-TEAM CNN path ('cnn') are built; the GRU/PFGRU core is SURVEY.md "
-                                      "section 8 row f2")
+        if self.actor_critic_architecture not in ("ff", "mlp", "cnn", "rnn"):
+            raise ValueError("Unsupported Neural Network type requested")      # ppo.py:666-667
         if self.render or self.save_gif:
             raise NotImplementedError("rendering is outside the hot path")
         if self.seed:
@@ -125,6 +124,14 @@ class train_PPO:
                                           global_critic_flag=self.global_critic_flag,
                                           use_predictor=bool(kw.get("use_predictor", True)),
                                           predictor_hidden_size=int(kw.get("predictor_hidden_size", 24)))
+            return
+        if self.actor_critic_architecture == "rnn":                           # RAD-A2C: GRU actor-critic + PFGRU (rada2c.py)
+            kw.setdefault("seed", self.seed)
+            self.agents = {i: RNNAgentPPO(id=i, device=self.vec.device, **kw) for i in range(self.number_of_agents)}
+            for i, ag in self.agents.items():
+                ag.sync_params()
+                self.loggers[i].setup_pytorch_saver(ag.agent)                  # train.py:221-226
+            self.collector = RNNCollector(self.vec, self.agents, self.steps_per_epoch, self.steps_per_episode)
             return
         self.agents = {i: VecAgentPPO(id=i, actor_critic_architecture=self.actor_critic_architecture,
                                       device=self.vec.device, **kw) for i in range(self.number_of_agents)}
@@ -185,6 +192,9 @@ class train_PPO:
             saving = self.rank == 0 and ((epoch % self.save_freq == 0) or (epoch == self.total_epochs - 1))
             if saving:
                 self.save()                                                             # train.py:552-561 (before the update)
+            if epoch > 99 and self.actor_critic_architecture == "rnn":                  # train.py:563-566
+                for ag in self.agents.values():
+                    ag.reduce_pfgru_training()
             results = self.collector.update()
             self.epochs_done = epoch + 1
             if saving:

@@ -768,6 +768,136 @@ def gen_loss():
     print("wrote rada2c_loss.npz")
 
 
+def gen_rada2c_core():
+    """the RAD-A2C core exactly as main.py:541-553 instantiates it --
+    RNNModelActorCritic(obs_dim=11, act_dim=8, hidden=[[24]], hidden_sizes_pol=[[32]], hidden_sizes_val=[[32]],
+    hidden_sizes_rec=[24], net_type="rnn") (NeuralNetworkCores/RADA2C_core.py:477-607: GRU(13 -> 24) + Woms / Valms heads +
+    PFGRUCell(40, 3, 3, 24, 0.7, True, "tanh")) -- driven by the reference's own methods:
+      step      a 14-step episode through ac.step with the hidden state carried (:528-548)
+      rada2c    AgentPPO.update_rada2c (ppo.py:1150-1281) on 5 episodes with the REAL grad_step (:550-566, BPTT through the GRU)
+      model     AgentPPO.update_model (ppo.py:1047-1148), one iteration: the PFGRU regression / ELBO loss, clip, Adam step
+    Every random draw is recorded: GRU h0 and particle h0 (reset_hidden), reparameterisation noise (replayed generator state),
+    resampling indices (torch.multinomial wrapped), sampled actions."""
+    import types
+    import torch
+    from algos.multiagent import ppo as RP
+    from algos.multiagent.NeuralNetworkCores import RADA2C_core as R
+
+    torch.manual_seed(41)
+    ac = R.RNNModelActorCritic(obs_dim=11, act_dim=8, hidden=[[24]], hidden_sizes_pol=[[32]], hidden_sizes_val=[[32]],
+                               hidden_sizes_rec=[24], net_type="rnn", seed=41)
+    ac.set_mode("eval")
+    res = {"sd_" + k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+    eps_log, idx_log, hid_log = [], [], []
+    orig_rep = ac.model.reparameterize
+
+    def rec_rep(mean, var):
+        st = torch.get_rng_state()
+        out = orig_rep(mean, var)
+        end = torch.get_rng_state()
+        torch.set_rng_state(st)
+        eps_log.append(torch.FloatTensor(var.shape).normal_().clone())
+        assert torch.equal(torch.get_rng_state(), end)
+        return out
+    ac.model.reparameterize = rec_rep
+    orig_mn = torch.multinomial
+
+    def rec_mn(*a, **k):
+        r = orig_mn(*a, **k)
+        if r.shape[-1] == 40:                    # the resampling draw (Categorical.sample also goes through torch.multinomial)
+            idx_log.append(r.clone())
+        return r
+    orig_reset = ac.reset_hidden
+
+    def rec_reset(batch_size=1):
+        h = orig_reset(batch_size)
+        hid_log.append((h[0][0].clone(), h[0][1].clone(), h[1].clone()))
+        return h
+    torch.multinomial = rec_mn
+    rng = np.random.default_rng(43)
+
+    def episode_obs(n):
+        o = rng.uniform(0.0, 1.0, size=(n, 11)).astype(np.float32)
+        o[:, 0] = rng.normal(size=n).astype(np.float32) * 1.5            # standardised reading
+        return o
+    try:
+        # ---- step: one episode, hidden carried
+        T = 14
+        obs = episode_obs(T)
+        hidden = rec_reset()
+        eps_log.clear(); idx_log.clear()
+        acts, logps, vals, locs, gh = [], [], [], [], []
+        for t in range(T):
+            r, _ = ac.step(obs[t], hidden)
+            hidden = r.hiddens
+            acts.append(int(r.action)); logps.append(float(r.action_logprob)); vals.append(np.asarray(r.state_value).reshape(-1)[0])
+            locs.append(np.asarray(r.loc_pred).reshape(2).copy()); gh.append(hidden[1].detach().numpy().reshape(-1).copy())
+        res.update(step_obs=obs, step_pf_h0=hid_log[-1][0].numpy(), step_gru_h0=hid_log[-1][2].numpy().reshape(-1),
+                   step_eps=torch.stack(eps_log).numpy(), step_idx=torch.stack(idx_log).numpy().reshape(T, -1).astype(np.int64),
+                   step_act=np.array(acts, dtype=np.int64), step_logp=np.array(logps, dtype=np.float32),
+                   step_val=np.array(vals, dtype=np.float32), step_loc=np.stack(locs).astype(np.float32), step_gru_h=np.stack(gh))
+        # ---- episodes for the two updates (column layout of PPOBuffer.get's ep_form: obs 0:11 | adv | ret | logp | act | src 15:17)
+        lens = [9, 14, 6, 11, 8]
+        eps = []
+        for n in lens:
+            o = episode_obs(n)
+            act = rng.integers(0, 8, size=n).astype(np.float32)
+            adv = rng.normal(size=n).astype(np.float32)
+            ret = rng.normal(size=n).astype(np.float32)
+            logp_old = (np.log(1.0 / 8.0) + rng.normal(size=n) * 0.05).astype(np.float32)
+            src = np.tile(rng.uniform(300.0, 2400.0, size=(1, 2)).astype(np.float32), (n, 1))
+            eps.append(np.concatenate([o, adv[:, None], ret[:, None], logp_old[:, None], act[:, None], src], axis=1))
+        res.update({f"ep{i}": e for i, e in enumerate(eps)})
+        res["n_eps"] = np.int64(len(eps))
+        opt = RP.OptimizationStorage(critic_flag=False, pi_optimizer=torch.optim.Adam(ac.pi.parameters(), lr=3e-4), critic_optimizer=None,
+                                     model_optimizer=torch.optim.Adam(ac.model.parameters(), lr=5e-3))
+        me = types.SimpleNamespace(minibatch=1, agent=ac, agent_optimizer=opt, clip_ratio=0.2, alpha=0.1, target_kl=0.07,
+                                   env_height=2500.0, reset_hidden=rec_reset, train_pfgru_iters=1,
+                                   bp_args=RP.BpArgs(bp_decay=0.1, l2_weight=1.0, l1_weight=0.0, elbo_weight=1.0, area_scale=2500.0))
+        data = dict(ep_form=[[torch.from_numpy(e.copy())] for e in eps])
+        # ---- update_rada2c (the policy side first: update_model changes the PFGRU weights that feed loc_pred)
+        np.random.seed(3)
+        order = np.random.choice(np.arange(0, len(eps)), size=len(eps), replace=False)
+        np.random.seed(3)
+        hid_log.clear(); eps_log.clear(); idx_log.clear()
+        before = {k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+        loss, info, term, ploss = RP.AgentPPO.update_rada2c(me, data, min_iterations=len(eps), logger=None)
+        grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad.detach().clone()).numpy() for k, v in ac.pi.named_parameters()}
+        res.update({"a2c_grad_" + k: v for k, v in grads.items()})
+        res.update({"a2c_after_" + k: v.detach().clone().numpy() for k, v in ac.state_dict().items()})
+        res.update(a2c_order=order, a2c_loss=np.float32(loss.item()), a2c_kl=np.float32(info["kl"]), a2c_ent=np.float32(info["ent"]),
+                   a2c_cf=np.float32(info["cf"]), a2c_val_loss=np.float32(info["val_loss"]), a2c_term=np.bool_(term),
+                   a2c_locloss=np.float32(float(ploss)))
+        off = 0
+        for k, ei in enumerate(order):                                     # draws in the order the reference consumed them
+            n = lens[int(ei)]
+            res[f"a2c_pf_h0_{k}"] = hid_log[k][0].numpy(); res[f"a2c_gru_h0_{k}"] = hid_log[k][2].numpy().reshape(-1)
+            res[f"a2c_eps_{k}"] = torch.stack(eps_log[off:off + n]).numpy()
+            res[f"a2c_idx_{k}"] = torch.stack(idx_log[off:off + n]).numpy().reshape(n, -1).astype(np.int64)
+            off += n
+        assert off == len(eps_log) == len(idx_log) and len(hid_log) == len(eps)
+        print("update_rada2c: loss", loss.item(), "kl", float(info["kl"]), "val_loss", float(info["val_loss"]), "term", term)
+        # ---- update_model: one iteration over the episodes in list order
+        hid_log.clear(); eps_log.clear(); idx_log.clear()
+        mloss = RP.AgentPPO.update_model(me, data)
+        mg = {k: (torch.zeros_like(v) if v.grad is None else v.grad.detach().clone()).numpy() for k, v in ac.model.named_parameters()}
+        res.update({"model_grad_" + k: v for k, v in mg.items()})                 # after clip_grad_norm_(., 5) (:1137)
+        res.update({"model_after_" + k: v.detach().clone().numpy() for k, v in ac.model.state_dict().items()})
+        res["model_loss"] = np.float32(mloss.item())
+        off = 0
+        for k, n in enumerate(lens):
+            res[f"model_pf_h0_{k}"] = hid_log[k][0].numpy()
+            res[f"model_eps_{k}"] = torch.stack(eps_log[off:off + n]).numpy()
+            res[f"model_idx_{k}"] = torch.stack(idx_log[off:off + n]).numpy().reshape(n, -1).astype(np.int64)
+            off += n
+        assert off == len(eps_log)
+        print("update_model: loss", mloss.item())
+    finally:
+        torch.multinomial = orig_mn
+    np.savez_compressed(os.path.join(OUT, "rada2c_core.npz"), **res)
+    print("wrote rada2c_core.npz", len(res), "arrays")
+
+
 def gen_cnn_loss():
     """Row P6, CNN branch: AgentPPO.compute_batched_losses_pi / compute_loss_pi (algos/multiagent/ppo.py:903-997) and
     compute_batched_losses_critic / compute_loss_critic (:999-1045) as the reference wrote them, over the reference's
@@ -878,7 +1008,7 @@ if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "pfgru", "train", "loss", "cnnloss", "refresh"]
+    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "pfgru", "train", "loss", "cnnloss", "refresh", "rada2c"]
     if "env" in which:
         gen_env_scenarios()
     if "envforms" in which:
@@ -905,3 +1035,5 @@ if __name__ == "__main__":
         gen_cnn_loss()
     if "refresh" in which:
         gen_refresh()
+    if "rada2c" in which:
+        gen_rada2c_core()

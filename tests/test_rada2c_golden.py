@@ -1,0 +1,132 @@
+"""Row f2: radiation_ppo_amd.rada2c against tests/golden/rada2c_core.npz -- the reference's RNNModelActorCritic
+(NeuralNetworkCores/RADA2C_core.py:477-607) driven by ITS OWN step / grad_step and by AgentPPO.update_rada2c / update_model
+(algos/multiagent/ppo.py:1047-1281), with every random draw recorded (generator: tests/golden/make_golden.py gen_rada2c_core).
+float32 arithmetic, different batching: rtol 1e-4, atol 1e-6 on activations; gradients rtol 2e-3 / atol 2e-6 (BPTT sums)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from radiation_ppo_amd.rada2c import EpisodeBatch, RNNAgentPPO, RNNModelActorCritic, RecordedDraws, pack_episodes
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rada2c_core.npz"))
+T = lambda k: torch.from_numpy(np.asarray(G[k]))
+
+
+def _agent(**kw):
+    ag = RNNAgentPPO(id=0, device="cpu", alpha=0.1, clip_ratio=0.2, target_kl=0.07, env_height=2500.0, train_pfgru_iters=1,
+                     actor_learning_rate=3e-4, pfgru_learning_rate=5e-3, **kw)
+    sd = {k[3:]: T(k) for k in G.files if k.startswith("sd_")}
+    assert set(sd) == set(ag.agent.state_dict()), "parameter names differ from the reference's state_dict"
+    ag.agent.load_state_dict(sd)
+    return ag
+
+
+def test_state_dict_names_and_shapes_match_the_reference():
+    ac = RNNModelActorCritic()
+    ref = {k[3:]: G[k].shape for k in G.files if k.startswith("sd_")}
+    assert {k: tuple(v.shape) for k, v in ac.state_dict().items()} == {k: tuple(v) for k, v in ref.items()}
+
+
+def test_step_sequence_matches_reference_step():
+    """ac.step (:528-548) 14 times with the hidden state carried: PFGRU prediction, GRU state, value and the log-probability of
+    the action the reference sampled."""
+    ag = _agent()
+    ac = ag.agent
+    obs = T("step_obs")
+    h = T("step_pf_h0").unsqueeze(0)
+    p = torch.full((1, 40), float(np.log(1.0 / 40)), dtype=torch.float32)
+    g = T("step_gru_h0").unsqueeze(0)
+    with torch.no_grad():
+        for t in range(obs.shape[0]):
+            loc, (h, p) = ac.model(obs[t:t + 1, :3], (h, p), T("step_eps")[t].unsqueeze(0), resample_idx=T("step_idx")[t].unsqueeze(0))
+            assert torch.allclose(loc[0], T("step_loc")[t], rtol=1e-4, atol=1e-6), t
+            logits, val, g = ac.policy_step(obs[t:t + 1], loc, g)
+            assert torch.allclose(g[0], T("step_gru_h")[t], rtol=1e-4, atol=1e-6), t
+            assert torch.allclose(val[0], T("step_val")[t], rtol=1e-4, atol=1e-6), t
+            logp = torch.log_softmax(logits, -1)[0, int(G["step_act"][t])]
+            assert torch.allclose(logp, T("step_logp")[t], rtol=1e-4, atol=1e-6), t
+
+
+def _episodes():
+    n = int(G["n_eps"])
+    eps = [G[f"ep{i}"] for i in range(n)]
+    lens = [e.shape[0] for e in eps]
+    # one env whose column is the concatenation of the episodes: exactly what the reference's ep_form describes
+    cat = np.concatenate(eps, 0)
+    cut = np.zeros(cat.shape[0], dtype=np.uint8)
+    cut[np.cumsum(lens) - 1] = 1
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).unsqueeze(1)
+    B = pack_episodes(f(cat[:, :11]), f(cat[:, 14].astype(np.int64)), f(cat[:, 11]), f(cat[:, 12]), f(cat[:, 13]), f(cat[:, 15:17]),
+                      f(cut), n_total=1)
+    return B, lens
+
+
+def test_pack_episodes_layout():
+    B, lens = _episodes()
+    assert B.X.shape == (max(lens), len(lens), 11) and B.lens.tolist() == lens
+    for e, n in enumerate(lens):
+        assert torch.equal(B.X[:n, e], T(f"ep{e}")[:, :11]) and not B.valid[n:, e].any() and B.valid[:n, e].all()
+    assert torch.allclose(B.w.sum(), torch.tensor(1.0)) and torch.allclose(B.w_ep, torch.full((len(lens),), 1.0 / len(lens)))
+
+
+def _draws(prefix, order, lens, L, with_gru):
+    E = len(lens)
+    pf = torch.zeros(E, 40, 24); gru = torch.zeros(E, 24)
+    eps = torch.zeros(L, E, 40, 24); idx = torch.zeros(L, E, 40, dtype=torch.int64)
+    for k, e in enumerate(order):                      # draw set k was consumed by episode order[k]
+        e = int(e); n = lens[e]
+        pf[e] = T(f"{prefix}_pf_h0_{k}")
+        if with_gru:
+            gru[e] = T(f"{prefix}_gru_h0_{k}")
+        eps[:n, e] = T(f"{prefix}_eps_{k}"); idx[:n, e] = T(f"{prefix}_idx_{k}")
+    return RecordedDraws(pf, gru, eps, idx)
+
+
+def test_update_rada2c_matches_reference():
+    """Loss, KL, entropy, clip fraction, value loss, every pi gradient and the parameters after the Adam step."""
+    ag = _agent()
+    B, lens = _episodes()
+    d = _draws("a2c", G["a2c_order"], lens, B.X.shape[0], True)
+    s, term = ag.update_rada2c(B, 0, draws_for=lambda it, sl: d)
+    assert term == bool(G["a2c_term"])
+    for got, key in ((s[4], "a2c_loss"), (s[0], "a2c_kl"), (s[1], "a2c_ent"), (s[2], "a2c_cf"), (s[3], "a2c_val_loss")):
+        assert np.isclose(got, float(G[key]), rtol=1e-4, atol=1e-6), (key, got, float(G[key]))
+    after = ag.agent.state_dict()
+    for name, prm in ag.agent.pi.named_parameters():
+        want = T("a2c_grad_" + name)
+        assert torch.allclose(prm.grad, want, rtol=2e-3, atol=2e-6), (name, (prm.grad - want).abs().max())
+        assert torch.allclose(after["pi." + name], T("a2c_after_pi." + name), rtol=1e-4, atol=2e-6), name
+
+
+def test_update_model_matches_reference():
+    """The PFGRU loss of update_model (regression + ELBO, bp-decay weights), its clipped gradients and the Adam step.  The
+    reference ran update_rada2c first (pi only), so the PFGRU weights are still the initial ones."""
+    ag = _agent()
+    B, lens = _episodes()
+    d = _draws("model", np.arange(len(lens)), lens, B.X.shape[0], False)
+    loss = ag.update_model(B, draws_for=lambda it, sl: d)
+    assert np.isclose(loss, float(G["model_loss"]), rtol=1e-4), (loss, float(G["model_loss"]))
+    after = ag.agent.model.state_dict()
+    for name, prm in ag.agent.model.named_parameters():
+        want = T("model_grad_" + name)
+        assert torch.allclose(prm.grad, want, rtol=2e-3, atol=2e-6), (name, (prm.grad - want).abs().max())
+        # Adam's first step is lr * g / (|g| + 1e-8): where the gradient itself is ~1e-8 the step amplifies float32 noise, so
+        # those elements are only held to |step| <= lr
+        big = want.abs() > 1e-6
+        diff = (after[name] - T("model_after_" + name)).abs()
+        assert (diff[big] <= 5e-6 + 1e-4 * after[name][big].abs()).all() and (diff <= 5e-3 + 1e-6).all(), name
+
+
+def test_hash_draw_update_runs_and_is_deterministic():
+    """The product path's own draws: two agents with the same seeds end an update with identical parameters; the loss is finite."""
+    outs = []
+    for _ in range(2):
+        ag = _agent()
+        ag.train_pi_iters = 3
+        B, _ = _episodes()
+        r = ag.update_agent(B)
+        assert np.isfinite([r.loss_policy, r.loss_critic, r.loss_predictor, r.kl_divergence, r.LocLoss]).all() and 1 <= r.stop_iteration <= 3
+        outs.append(torch.cat([p.detach().reshape(-1) for p in ag.agent.parameters()]))
+    assert torch.equal(outs[0], outs[1])

@@ -1,0 +1,117 @@
+"""Row f2 on the GPU: the RAD-A2C ('rnn') collector and trainer.  The collector is replayed env by env through the pinned
+train-loop oracle (oracle/train_loop_oracle.train_loop_trace, RAD-A2C branch) exactly like the MLP collectors; the networks'
+arithmetic is pinned on the CPU (tests/test_rada2c_golden.py); here: the stored log-probabilities / values are those of the
+carried GRU + K11 particle states, hidden states restart at episode boundaries, and train_PPO runs the architecture end to end."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from test_ppo_gpu import SEED, _replay_check  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(N, T, L, obst=0, seed=SEED, base=0):
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
+    torch.manual_seed(4)
+    env = RadSearchVec(N, number_agents=1, obstruction_count=obst, enforce_grid_boundaries=True, seed=seed, env_id_base=base)
+    agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, train_pi_iters=3, train_pfgru_iters=2, seed=3)}
+    with torch.no_grad():
+        for p in agents[0].agent.pi.parameters():
+            p.mul_(2.0)                              # make the policy visibly non-uniform
+    return env, agents, RNNCollector(env, agents, T, L)
+
+
+@pytest.mark.parametrize("obst", [0, 2])
+def test_rnn_collector_replays_through_oracle(obst):
+    N, T, L = 64, 40, 12
+    env, agents, col = _make(N, T, L, obst)
+    col.collect()
+    _replay_check(col, agents, N, T, L, obst, stride=5)
+    buf = col.buf
+    assert torch.isfinite(buf.logp).all() and (buf.logp <= 0).all() and torch.isfinite(buf.val).all()
+    assert int(buf.act.min()) >= 0 and int(buf.act.max()) <= 7
+
+
+def test_rnn_collector_state_semantics():
+    """Replay the stored observations through the agent's own modules with a twin particle bank: the stored log-probabilities
+    and values are reproduced only when the GRU / particle states are carried inside an episode and restarted at every cut."""
+    from radiation_ppo_amd.pfgru import PredictorBank, _s64, hash_uniform
+    N, T, L = 32, 30, 9
+    env, agents, col = _make(N, T, L, base=64)
+    col.collect()
+    ac = agents[0].agent
+    buf = col.buf
+    twin = PredictorBank(N, 1, seed=SEED, env_id_base=64, carry_hidden=True, device="cuda")
+    twin.cells[0] = ac.model
+    begun = torch.zeros(N, dtype=torch.int64, device="cuda")
+    h = torch.zeros(N, 24, device="cuda")
+    gidx = torch.arange(24, dtype=torch.int64, device="cuda")
+
+    def restart(mask):
+        nonlocal begun, h
+        twin.reset(mask)
+        m = torch.ones(N, dtype=torch.bool, device="cuda") if mask is None else mask
+        begun = begun + m.long()
+        key = (twin._base * 1000003) ^ ((begun.view(1, -1) * 8 + 5) * _s64(0xA24BAED4963EE407))
+        h0 = ac.gru_h0(hash_uniform(key.unsqueeze(-1) * 1048583 + gidx.view(1, 1, -1)))[0]
+        h = torch.where(m.view(-1, 1), h0, h)
+    restart(None)
+    with torch.no_grad():
+        for t in range(T):
+            x = buf.obs[t]
+            loc = twin.predict(x)
+            logits, v, h = ac.policy_step(x[:, 0], loc[:, 0], h)
+            lp = torch.log_softmax(logits, -1).gather(-1, buf.act[t, :, 0].unsqueeze(-1)).squeeze(-1)
+            assert torch.allclose(lp, buf.logp[t, :, 0], rtol=1e-5, atol=1e-6), t
+            assert torch.allclose(v, buf.val[t, :, 0], rtol=1e-5, atol=1e-6), t
+            cut = buf.cut[t, :, 0].bool()
+            boot = cut & (buf.last_val[t, :, 0] != 0)
+            twin.calls += boot.long()                    # the collector's bootstrap step consumed one prediction
+            if t < T - 1:
+                restart(cut)
+    # an epoch's first step starts from fresh hidden states too (train.py:322-329)
+    col.collect()
+    assert torch.isfinite(col.buf.val).all()
+
+
+def test_rnn_collector_is_sharding_invariant():
+    N, T, L = 32, 24, 8
+    full = _make(N, T, L)[2]
+    half = _make(N // 2, T, L, base=N // 2)[2]
+    full.collect(); half.collect()
+    for name in ("obs", "act", "rew", "cut"):
+        a, b = getattr(full.buf, name)[:, N // 2:], getattr(half.buf, name)
+        assert torch.equal(a, b), name
+    assert torch.allclose(full.buf.logp[:, N // 2:], half.buf.logp, rtol=1e-5, atol=1e-6)
+
+
+def test_train_ppo_rnn_end_to_end(tmp_path):
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNModelActorCritic
+    from radiation_ppo_amd.train import train_PPO
+    vec = RadSearchVec(64, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED)
+    sim = train_PPO(env=vec, logger_kwargs=dict(output_dir=str(tmp_path)), seed=2, number_of_agents=1, actor_critic_architecture="rnn",
+                    global_critic_flag=False, steps_per_epoch=36, steps_per_episode=12, total_epochs=2, save_freq=1,
+                    ppo_kwargs=dict(train_pi_iters=3, train_pfgru_iters=2, alpha=0.1))
+    before = torch.cat([p.detach().reshape(-1).clone() for p in sim.agents[0].agent.parameters()])
+    sim.train()
+    after = torch.cat([p.detach().reshape(-1) for p in sim.agents[0].agent.parameters()])
+    assert not torch.equal(before, after) and torch.isfinite(after).all()
+    rows = sim.loggers[0].rows
+    assert len(rows) == 2
+    for r in rows:
+        for k in ("loss_policy", "loss_critic", "loss_predictor", "LocLoss", "kl_divergence", "Entropy", "MeanVVals"):
+            assert np.isfinite(float(r[k])), (k, r[k])
+        assert float(r["loss_predictor"]) > 0 and 1 <= int(r["stop_iteration"]) <= 3
+    # the saved module loads into the reference-shaped network (pyt_save/model.pt, epoch_logger.py:216-284)
+    sd = torch.load(os.path.join(str(tmp_path), "0_agent", "pyt_save", "model.pt"), map_location="cpu")
+    RNNModelActorCritic().load_state_dict(sd)
+    with pytest.raises(Exception, match="global critic"):
+        from radiation_ppo_amd.rada2c import RNNCollector
+        RNNCollector(vec, sim.agents, 36, 12, global_critic_flag=True)
