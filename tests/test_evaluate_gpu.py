@@ -12,17 +12,18 @@ from oracle.radsearch_oracle import PhiloxDraws, RadSearchOracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("obst", [0, 3])
-def test_monte_carlo_evaluation_matches_oracle_replay(obst):
+@pytest.mark.parametrize("obst,arch", [(0, "ff"), (3, "ff"), (2, "rnn")])
+def test_monte_carlo_evaluation_matches_oracle_replay(obst, arch):
     from radiation_ppo_amd.evaluate import run_test_environments, sample_test_environments
     from radiation_ppo_amd.ppo import VecAgentPPO
+    from radiation_ppo_amd.rada2c import RNNAgentPPO
     torch.manual_seed(9)
     E, R, L, seed = 6, 5, 40, 123
     sets = sample_test_environments(E, obstruction_count=obst, seed=77)
     assert sorted(sets) == [f"env_{i}" for i in range(E)] and len(sets["env_0"]) == (5 if obst else 4)
-    agent = VecAgentPPO(id=0, steps_per_epoch=480, steps_per_episode=L)
+    agent = VecAgentPPO(id=0, steps_per_epoch=480, steps_per_episode=L) if arch == "ff" else RNNAgentPPO(id=0, steps_per_episode=L)
     with torch.no_grad():                                           # a decisive policy finds sources within 40 steps sometimes
-        for p in agent.agent.actor.parameters():
+        for p in (agent.agent.actor if arch == "ff" else agent.agent.pi).parameters():
             p.mul_(4.0)
     results, summary, actions = run_test_environments(agent, sets, montecarlo_runs=R, steps_per_episode=L, obstruction_count=obst,
                                                       seed=seed, return_actions=True)
@@ -117,3 +118,23 @@ def test_evaluate_ppo_driver_reads_a_saved_set_and_saved_models(tmp_path):
     assert len(results) == 4 and summary["completed_runs"] == 12 and 0.0 <= summary["success_rate"] <= 1.0
     with pytest.raises(ValueError):
         evaluate_PPO(dict(test_env_path="x", obstruction_count=-1))
+
+
+def test_evaluate_ppo_driver_with_the_recurrent_agent(tmp_path):
+    """evaluate_PPO with actor_critic_architecture='rnn': pyt_save/model.pt written by train_PPO, episodes with carried hidden states."""
+    joblib = pytest.importorskip("joblib")
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.evaluate import evaluate_PPO, sample_test_environments
+    from radiation_ppo_amd.train import train_PPO
+    sets = sample_test_environments(4, obstruction_count=0, seed=3)
+    os.makedirs(tmp_path / "sets")
+    joblib.dump(sets, str(tmp_path / "sets" / "test_env_dict_obs0_high_v4"))
+    env = RadSearchVec(16, number_agents=1, obstruction_count=0, enforce_grid_boundaries=True, seed=2)
+    train_PPO(env=env, logger_kwargs=dict(output_dir=str(tmp_path / "models")), ppo_kwargs=dict(train_pi_iters=1, train_pfgru_iters=1),
+              seed=2, number_of_agents=1, actor_critic_architecture="rnn", global_critic_flag=False, steps_per_epoch=12,
+              steps_per_episode=6, total_epochs=1).train()
+    ev = evaluate_PPO(dict(test_env_path=str(tmp_path / "sets"), obstruction_count=0, snr="high", episodes=3, montecarlo_runs=4,
+                           model_path=str(tmp_path / "models"), actor_critic_architecture="rnn", number_of_agents=1,
+                           steps_per_episode=10, enforce_boundaries=True, seed=1))
+    results, summary = ev.evaluate()
+    assert len(results) == 3 and summary["completed_runs"] == 12 and 0.0 <= summary["success_rate"] <= 1.0
