@@ -85,3 +85,63 @@ def test_two_rank_update_equals_single_process():
     assert np.allclose(np.concatenate([res[0][2], res[1][2]]), adv_n.numpy(), rtol=1e-5, atol=1e-6)
     assert res[0][3] == res[1][3] == r1.stop_iteration
     assert abs(res[0][4] - r1.kl_divergence) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------- RAD-A2C ('rnn') under data parallelism
+def _rnn_columns(seed=5, T=30, N=8):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.rand(T, N, 11, generator=g)
+    act = torch.randint(0, 8, (T, N), generator=g)
+    adv, ret = torch.randn(T, N, generator=g), torch.randn(T, N, generator=g)
+    logp = torch.full((T, N), float(np.log(1 / 8)))
+    src = torch.rand(T, N, 2, generator=g) * 2000 + 200
+    cut = (torch.rand(T, N, generator=g) < 0.12).to(torch.uint8)
+    cut[-1] = 1
+    return obs, act, adv, ret, logp, src, cut
+
+
+def _rnn_update(lo, hi, n_total, base):
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, pack_episodes
+    torch.manual_seed(77)
+    ag = RNNAgentPPO(id=0, device="cpu", train_pi_iters=3, train_pfgru_iters=2, alpha=0.1, seed=1)
+    cols = [c[:, lo:hi].contiguous() for c in _rnn_columns()]
+    B = pack_episodes(*cols, n_total=n_total, env_id_base=base, seed=9, epoch=0)
+    return ag, ag.update_agent(B)
+
+
+def _rnn_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag, res = _rnn_update(rank * 4, rank * 4 + 4, 8, rank * 4)
+    flat = torch.cat([p.data.view(-1) for p in ag.agent.parameters()])
+    out.put((rank, flat.numpy(), res.stop_iteration, res.kl_divergence, res.loss_predictor, res.loss_policy))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_recurrent_update_equals_single_process():
+    """RNNAgentPPO.update_agent (PFGRU update + BPTT policy update) on two gloo ranks holding four env columns each == one
+    process holding all eight: episode weights carry 1 / global env count, draws are keyed by global env id, gradients and
+    statistics are summed over ranks (ppo.py:1139-1141, :1250-1256)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rnn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ag, one = _rnn_update(0, 8, 8, 0)
+    want = torch.cat([p.data.view(-1) for p in ag.agent.parameters()]).numpy()
+    assert np.array_equal(res[0][1], res[1][1])                       # the ranks stay in lock-step
+    # Adam's step is lr * m / (sqrt(v) + 1e-8): where a gradient is ~1e-8 the different summation order of the two ranks is
+    # amplified up to the step size, so all elements are held to the step size and 99.5 % to float32 accuracy
+    diff = np.abs(res[0][1] - want)
+    assert diff.max() <= 1.5e-2 and np.mean(diff <= 2e-6 + 2e-4 * np.abs(want)) >= 0.995, (diff.max(), np.mean(diff <= 2e-6 + 2e-4 * np.abs(want)))
+    assert res[0][2] == one.stop_iteration
+    assert np.isclose(res[0][3], one.kl_divergence, rtol=1e-3, atol=1e-6) and np.isclose(res[0][4], one.loss_predictor, rtol=1e-4)
+    assert np.isclose(res[0][5], one.loss_policy, rtol=1e-3, atol=1e-6)
