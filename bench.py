@@ -276,17 +276,26 @@ def run_config3(dev, iters: int = 2, warmup: int = 1):
     roll_gbs = ROLLOUT_BYTES_PER_ENV_STEP * N * T / (roll_ms * 1e-3) / 1e9
     # K1<true> on its own at this size (the lane function the rollout runs), HIP events
     k1 = time_step_kernel(env, reps=200)
+    # the same kernel with one obstacle layout shared by 64 envs (geom_group_size = 64), throughput for both
+    env64 = RadSearchVec(N, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED, geom_group_size=64, device=dev)
+    env64.reset()
+    k1s = time_step_kernel(env64, reps=200)
+    del env64
     out = {"workload": "single-agent RadSearch, 1 source + U{1..5} random rectangles per env, 8192 envs, 2x64 MLP, 480 steps/epoch",
            "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
            "update_adam_steps": stops,
            "roofline": grad_roofline(ev["rs_ppo_grad"], stops, ag[0].train_pi_iters, N * T),
+           "config5_note": "config 5 (32 768 envs x 4 agents + obstacles on 8 GPUs) has config 4's per-GPU workload: 4096 envs x 4 agents",
            "roofline_rollout": {"bound": "hbm", "kernel": "rs_rollout16_kernel<true>", "achieved": roll_gbs, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": roll_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": roll_ms,
                                 "bytes_per_launch": ROLLOUT_BYTES_PER_ENV_STEP * N * T, "us_per_lock_step": 1e3 * roll_ms / T,
                                 "note": "one launch = 480 lock-steps of 8192 envs with the policy in the loop; latency bound "
                                         "(f64 env chain + visibility tests per lane), not HBM bound"},
-           "roofline_env_step": {"bound": "hbm", "kernel": "rs_step_kernel<true>", "avg_launch_ms": k1["avg_ms"],
+           "roofline_env_step": {"bound": "hbm", "kernel": "rs_step4_kernel (obstacles: four lanes per env)", "avg_launch_ms": k1["avg_ms"],
+                                 "avg_launch_ms_shared_geometry_64": k1s["avg_ms"],
+                                 "env_only_steps_per_s": N / (k1["avg_ms"] * 1e-3),
+                                 "env_only_steps_per_s_shared_geometry_64": N / (k1s["avg_ms"] * 1e-3),
                                  "achieved": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "bytes_per_launch": K1_BYTES_PER_AGENT_STEP * N,

@@ -309,7 +309,7 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
  *   pred      [N][A][2]    location prediction (scaled coordinates, >= 0: the reference's MLP ends in a ReLU) */
 #define RS_PFGRU_PARTICLES 40
 #define RS_PFGRU_HIDDEN 24
-#define RS_PFGRU_WEIGHT_FLOATS 3376
+#define RS_PFGRU_WEIGHT_FLOATS 3472
 int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
                   const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
                   int32_t num_agents, rs_stream_t stream);

@@ -23,9 +23,10 @@ namespace {
 
 constexpr int PF_P = RS_PFGRU_PARTICLES, PF_H = RS_PFGRU_HIDDEN, PF_IN = 3, PF_K = PF_H + PF_IN;   // 40, 24, 3, 27
 // packed weights of one owner (floats), produced on the host (radiation_ppo_amd/pfgru.py: pack_weights):
-//   zr_t [27][48] (k-major; outputs 0..23 = fc_z, 24..47 = fc_r) | zr_b [48] | n_t [27][48] (0..23 mu, 24..47 var) | n_b [48]
+//   zr_t [28][48] (k-major, row 27 = 0; outputs 0..23 = fc_z, 24..47 = fc_r) | zr_b [48] | n_t [28][48] (0..23 mu, 24..47 var) | n_b [48]
 //   | o_w [27] | o_b [1] | pad to 16 | h0_t [24][24] (k-major) | h0_b [24] | h2_w [2][24] | h2_b [2] | pad
-constexpr int PF_ZR = 0, PF_ZRB = PF_ZR + PF_K * 48, PF_N = PF_ZRB + 48, PF_NB = PF_N + PF_K * 48, PF_O = PF_NB + 48,
+constexpr int PF_KP = 28;                                          // k rows padded to an even count: the products run two rows per block
+constexpr int PF_ZR = 0, PF_ZRB = PF_ZR + PF_KP * 48, PF_N = PF_ZRB + 48, PF_NB = PF_N + PF_KP * 48, PF_O = PF_NB + 48,
               PF_OB = PF_O + PF_K, PF_H0 = ((PF_OB + 1 + 15) / 16) * 16, PF_H0B = PF_H0 + PF_H * 24, PF_H2 = PF_H0B + 24,
               PF_H2B = PF_H2 + 48, PF_STRIDE = ((PF_H2B + 2 + 15) / 16) * 16;
 static_assert(PF_STRIDE == RS_PFGRU_WEIGHT_FLOATS, "include/radsearch.h: RS_PFGRU_WEIGHT_FLOATS");
@@ -52,6 +53,45 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit.  Two k rows (2 x s_load_dwordx16 per
+// 16-output chunk) form a block; the next block's rows are requested before the current block's 32 FMAs and a scheduling
+// barrier closes every block, so at most two blocks (64 SGPRs) are live: without it the scheduler hoists dozens of the
+// (independent) loads, runs out of SGPRs and spills them through v_writelane / v_readlane (measured: 1 389 loads and 2 756
+// v_readlane in 21 k instructions for this kernel, 419 us per step at config 4).
+template <int WOFF, int BOFF, typename F>
+__device__ __forceinline__ void pf_matvec48(cmem_t W, F cval, float (&out)[48]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float acc[16], wa[32], wb[32];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[BOFF + 16 * ch + o];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) wa[i] = W[WOFF + (i >> 4) * 48 + 16 * ch + (i & 15)];
+#pragma unroll
+        for (int b = 0; b < PF_KP / 2; ++b) {
+            if (b + 1 < PF_KP / 2) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) wb[i] = W[WOFF + (2 * (b + 1) + (i >> 4)) * 48 + 16 * ch + (i & 15)];
+            }
+            const float c0 = cval(2 * b), c1 = cval(2 * b + 1);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[o], c0, acc[o]);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[16 + o], c1, acc[o]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wa[i] = wb[i];
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            // materialise the result here: otherwise the compiler sinks each output's FMA chain to its use (to save VGPRs) and
+            // re-reads a whole 16-dword row per FMA (seen in the ISA: one s_load_dwordx16 + s_waitcnt per v_fmac)
+            asm volatile("" : "+v"(acc[o]));
+            out[16 * ch + o] = acc[o];
+        }
+    }
+}
+
 struct PfArgs {
     const float* w;           // [A][PF_STRIDE]
     const float* obs;         // [N][A][11]
@@ -69,7 +109,7 @@ struct PfArgs {
 constexpr int PF_ROW = PF_H + 1;                                   // odd row stride: conflict-free row writes and column reads
 constexpr int PF_LDS_WAVE = PF_P * PF_ROW * 4 + PF_P * 8 + 64 * 4; // h tile, cdf (f64), p1 / mean
 
-__global__ void __launch_bounds__(256) rs_pfgru_kernel(PfArgs a_) {
+__global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long wv = (long long)blockIdx.x * 4 + wid;
@@ -108,36 +148,25 @@ __global__ void __launch_bounds__(256) rs_pfgru_kernel(PfArgs a_) {
 
     // ---- gates: z | r = sigmoid(W_zr [h0, x] + b)
     float g[48];
+    pf_matvec48<PF_ZR, PF_ZRB>(W, [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : (k < PF_K ? x[(k >= PF_H && k < PF_K) ? k - PF_H : 0] : 0.0f); }, g);
 #pragma unroll
-    for (int o = 0; o < 48; ++o) g[o] = W[PF_ZRB + o];
-#pragma unroll
-    for (int k = 0; k < PF_K; ++k) {
-        const float c = (k < PF_H) ? h0[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H];
-#pragma unroll
-        for (int o = 0; o < 48; ++o) g[o] = fmaf(W[PF_ZR + k * 48 + o], c, g[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < 48; ++o) g[o] = 1.0f / (1.0f + expf(-g[o]));
+    for (int o = 0; o < 48; ++o) g[o] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * g[o]));   // sigmoid: v_exp_f32, v_rcp_f32 (1 ulp each)
     // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b
     float m[48];
-#pragma unroll
-    for (int o = 0; o < 48; ++o) m[o] = W[PF_NB + o];
-#pragma unroll
-    for (int k = 0; k < PF_K; ++k) {
-        const float c = (k < PF_H) ? g[24 + (k < PF_H ? k : 0)] * h0[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H];
-#pragma unroll
-        for (int o = 0; o < 48; ++o) m[o] = fmaf(W[PF_N + k * 48 + o], c, m[o]);
-    }
+    pf_matvec48<PF_N, PF_NB>(W, [&](int k) -> float { return (k < PF_H) ? g[24 + (k < PF_H ? k : 0)] * h0[k < PF_H ? k : 0] : (k < PF_K ? x[(k >= PF_H && k < PF_K) ? k - PF_H : 0] : 0.0f); }, m);
     float h1[PF_H];
 #pragma unroll
     for (int u = 0; u < PF_H; ++u) {
         const uint64_t hx = pf_hash(pk + (uint64_t)u);
         const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
         const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
-        const float eps = sqrtf(-2.0f * logf(u1)) * cosf(6.2831855f * u2);                   // Box-Muller
+        // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
+        // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
+        const float eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
         const float var = m[24 + u];
-        const float sp = (var > 20.0f) ? var : log1pf(expf(var));                            // F.softplus
-        const float nv = tanhf(m[u] + eps * sp);
+        const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
+        const float y = m[u] + eps * sp;
+        const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
         h1[u] = (1.0f - g[u]) * nv + g[u] * h0[u];
     }
     // ---- observation likelihood, log-softmax over the particles

@@ -65,20 +65,20 @@ def hash_normal(key: torch.Tensor) -> torch.Tensor:
 
 
 # packed per-owner weights of csrc/rs_pfgru.hip (floats): offsets of the blocks and the owner stride
-_PF_K = 27
+_PF_K = 27                      # the two [k][48] blocks are padded to 28 k rows (row 27 = 0)
 _PF_ZR, _PF_ZRB, _PF_N, _PF_NB, _PF_O, _PF_OB, _PF_H0, _PF_H0B, _PF_H2, _PF_H2B, PF_WEIGHT_FLOATS = (
-    0, 1296, 1344, 2640, 2688, 2715, 2720, 3296, 3320, 3368, 3376)
+    0, 1344, 1392, 2736, 2784, 2811, 2816, 3392, 3416, 3464, 3472)
 
 
 def pack_weights(cells) -> torch.Tensor:
-    """[A, PF_WEIGHT_FLOATS] float32: zr_t [27][48] | zr_b | n_t [27][48] | n_b | o_w [27] | o_b | h0_t [24][24] | h0_b | h2_w [2][24] | h2_b."""
+    """[A, PF_WEIGHT_FLOATS] float32: zr_t [28][48] | zr_b | n_t [28][48] | n_b | o_w [27] | o_b | h0_t [24][24] | h0_b | h2_w [2][24] | h2_b."""
     rows = []
     for c in cells:
         assert c.h_dim == 24 and c.num_particles == 40 and c.input_size == 3, "rs_pfgru_step is built for 40 particles x 24 units"
         w = torch.zeros(PF_WEIGHT_FLOATS, dtype=torch.float32, device=c.fc_z.weight.device)
-        w[_PF_ZR:_PF_ZRB] = torch.cat([c.fc_z.weight, c.fc_r.weight], 0).t().reshape(-1)
+        w[_PF_ZR:_PF_ZR + _PF_K * 48] = torch.cat([c.fc_z.weight, c.fc_r.weight], 0).t().reshape(-1)
         w[_PF_ZRB:_PF_N] = torch.cat([c.fc_z.bias, c.fc_r.bias], 0)
-        w[_PF_N:_PF_NB] = c.fc_n.weight.t().reshape(-1)
+        w[_PF_N:_PF_N + _PF_K * 48] = c.fc_n.weight.t().reshape(-1)
         w[_PF_NB:_PF_O] = c.fc_n.bias
         w[_PF_O:_PF_OB] = c.fc_obs.weight.reshape(-1)
         w[_PF_OB] = c.fc_obs.bias[0]
