@@ -114,7 +114,7 @@ class timed:
 
     def __enter__(self):
         self.ev = None
-        if EVENTS is not None:
+        if EVENTS is not None and not torch.cuda.is_current_stream_capturing():     # no timing events inside a graph capture
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record()
         return self

@@ -190,8 +190,8 @@ class PredictorBank:
     def reset(self, mask: Optional[torch.Tensor] = None) -> None:
         """reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: a new episode, fresh h0 ~ U[0,1), p0 = log(1/P)."""
         m1 = torch.ones(self.N, dtype=torch.bool, device=self.dev) if mask is None else mask.bool()
-        self.episode = self.episode + m1.long()
-        self.calls = torch.where(m1, torch.zeros_like(self.calls), self.calls)
+        self.episode.add_(m1.long())                      # counters change in place: a captured collector step refers to them
+        self.calls.masked_fill_(m1, 0)
         if self.impl == "hip":
             m8 = None if mask is None else m1.to(torch.uint8)
             with _lib.timed("rs_pfgru_reset"):
@@ -212,7 +212,11 @@ class PredictorBank:
         ver = tuple(p._version for c in self.cells for p in c.parameters())
         if getattr(self, "_pack_ver", None) != ver:
             with torch.no_grad():
-                self._wpack = pack_weights(self.cells)
+                w = pack_weights(self.cells)
+                if getattr(self, "_wpack", None) is None:
+                    self._wpack = w
+                else:
+                    self._wpack.copy_(w)                  # same address: a captured collector step keeps reading it
             self._pack_ver = ver
         return self._wpack
 
@@ -247,7 +251,7 @@ class PredictorBank:
                                                    None if m8 is None else m8.data_ptr(), 1 if self.carry_hidden else 0,
                                                    float(self.cells[0].resamp_alpha), self._pred.data_ptr(), N, A, self._stream()),
                            "rs_pfgru_step")
-            self.calls = self.calls + (1 if mask is None else mask.long())
+            self.calls.add_(1 if mask is None else mask.long())
             return self._pred.clone()
         W = self._stacked()
         k_eps, k_res = self._key(1), self._key(2)                                                           # [A, N]
@@ -280,7 +284,7 @@ class PredictorBank:
                 m = mask.bool()
                 self.h = torch.where(m.view(1, N, 1, 1), h1, self.h)
                 self.p = torch.where(m.view(1, N, 1), p1, self.p)
-        self.calls = self.calls + (1 if mask is None else mask.long())
+        self.calls.add_(1 if mask is None else mask.long())
         return loc.permute(1, 0, 2).contiguous()
 
     def state_dict(self, a: int):

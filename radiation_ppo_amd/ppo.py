@@ -413,6 +413,12 @@ class EpochStats:
         self.ret_max = torch.full((A,), float("-inf"), **f64)
         self.ret_min = torch.full((A,), float("inf"), **f64)
 
+    def zero_(self) -> None:
+        """Start a new epoch in place (the tensors keep their addresses: a captured collector step refers to them)."""
+        for t in (self.oob, self.done, self.ep_cnt, self.ep_len, self.ret_sum, self.ret_sq):
+            t.zero_()
+        self.ret_max.fill_(float("-inf")); self.ret_min.fill_(float("inf"))
+
     def step(self, out_of_bounds: torch.Tensor, done: torch.Tensor) -> None:
         self.oob += out_of_bounds.double().sum(dim=0)                        # [N,A] -> per agent id
         self.done += done.double().sum(dim=0)                                # terminals[id] (the env latch as agent id saw it)
@@ -422,14 +428,14 @@ class EpochStats:
         r = ep_ret.double()
         self.ret_sum += (r * m).sum(dim=0)
         self.ret_sq += (r * r * m).sum(dim=0)
-        self.ret_max = torch.maximum(self.ret_max, torch.where(m, r, torch.full_like(r, float("-inf"))).max(dim=0).values)
-        self.ret_min = torch.minimum(self.ret_min, torch.where(m, r, torch.full_like(r, float("inf"))).min(dim=0).values)
+        self.ret_max.copy_(torch.maximum(self.ret_max, torch.where(m, r, torch.full_like(r, float("-inf"))).max(dim=0).values))
+        self.ret_min.copy_(torch.minimum(self.ret_min, torch.where(m, r, torch.full_like(r, float("inf"))).min(dim=0).values))
         self.ep_len += (steps_in_ep.double() * over).sum()
         self.ep_cnt += over.double().sum()
 
     def result(self) -> Dict[str, torch.Tensor]:
-        return dict(DoneCount=self.done, OutOfBound=self.oob, EpCount=self.ep_cnt, EpLenSum=self.ep_len, EpRetSum=self.ret_sum,
-                    EpRetSqSum=self.ret_sq, EpRetMax=self.ret_max, EpRetMin=self.ret_min)
+        return dict(DoneCount=self.done.clone(), OutOfBound=self.oob.clone(), EpCount=self.ep_cnt.clone(), EpLenSum=self.ep_len.clone(),
+                    EpRetSum=self.ret_sum.clone(), EpRetSqSum=self.ret_sq.clone(), EpRetMax=self.ret_max.clone(), EpRetMin=self.ret_min.clone())
 
 
 class Collector:

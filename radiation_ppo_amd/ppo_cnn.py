@@ -172,7 +172,7 @@ class CNNCollector:
 
     def __init__(self, env: RadSearchVec, agents: Dict[int, CNNAgentPPO], steps_per_epoch: int, steps_per_episode: int,
                  global_critic_flag: bool = True, use_predictor: bool = True, predictor_hidden_size: int = 24,
-                 carry_hidden: bool = False):
+                 carry_hidden: bool = False, use_graph: bool = True):
         self.env, self.agents = env, agents
         self.T, self.L, self.N, self.A = steps_per_epoch, steps_per_episode, env.num_envs, env.number_agents
         self.team_reward = global_critic_flag
@@ -197,6 +197,16 @@ class CNNCollector:
         self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
         self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
         self.complete_len = torch.zeros(self.N, dtype=torch.int64, device=dev)
+        # one lock-step of the loop is ~60 small launches (maps, 5 trunk + head evaluations, sampling, env step, bootstrap
+        # round, resets): launch bound.  The step is therefore captured ONCE into a HIP graph and replayed T - 1 times per
+        # epoch (the epoch's last step, which raises epoch_end, runs eagerly).  Everything a step reads or writes lives at a
+        # fixed address: state is updated in place, the buffer row is addressed by a device-side step counter.
+        self.use_graph = use_graph
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._t = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._acc = EpochStats(self.A, dev)
+        self._row_act = torch.zeros(self.N, self.A, dtype=torch.int64, device=dev)
+        self._row_f = torch.zeros(3, self.N, self.A, dtype=torch.float32, device=dev)      # logp, val, last_val of the step
         self.obs = None
         # CNNBase.model (RADTEAM_core.py:1790-1795): one PFGRU cell per owner, all envs at once
         self.predictor: Optional[PredictorBank] = None
@@ -208,7 +218,7 @@ class CNNCollector:
 
     def start(self) -> None:
         obs, *_ = self.env.reset()
-        self.obs = obs.clone()
+        self.obs = obs.clone()                                      # from here on updated in place (fixed address)
         if self.predictor is not None:
             self.predictor.reset()                                  # ac.reset_hidden() (test_cnn/train.py:686)
 
@@ -234,64 +244,94 @@ class CNNCollector:
         return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
 
     @torch.no_grad()
+    def _step(self, epoch_ended: bool) -> None:
+        """One lock-step of train.py:332-548 for all envs; row self._t of the buffers is written, then self._t advances."""
+        env, buf, L, N, A = self.env, self.buf, self.L, self.N, self.A
+        acc, ti = self._acc, self._t
+        put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
+        critic, cells, pcells = self._round()
+        put(self.shared, critic); put(self.cells, cells); put(self.pcells, pcells)
+        env.action_uniforms(self._u)
+        v_shared = None
+        for a, ag in self.agents.items():
+            act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
+            if not ag.global_critic or v_shared is None:          # one evaluation serves every owner of a global critic
+                v_shared = ag._values((critic,))
+            self._row_act[:, a] = act
+            self._row_f[0, :, a] = logp
+            self._row_f[1, :, a] = v_shared
+            self._act8[:, a] = act.to(torch.int8)
+        put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
+        put(buf.obs, self.obs)
+        next_obs, rew, team, done, info = env.step(self._act8)
+        r_used = team.unsqueeze(1).expand(N, A) if self.team_reward else rew
+        put(buf.rew, r_used.contiguous())
+        self.ep_ret += r_used
+        self.steps_in_ep += 1
+        terminal = done.bool().any(dim=1)
+        acc.step(info["out_of_bounds"], done)
+        timeout = self.steps_in_ep == L
+        episode_over = terminal | timeout
+        cut = torch.ones_like(episode_over) if epoch_ended else episode_over
+        boot = cut if epoch_ended else timeout
+        put(buf.cut, cut.unsqueeze(1).to(torch.uint8).expand(N, A).contiguous())
+        self.obs.copy_(next_obs)
+        # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480);
+        # the maps of those envs see the final observation a second time, exactly as in the reference
+        bc = boot & cut
+        critic_b, _, _ = self._round(mask=bc)
+        vb = None
+        for a, ag in self.agents.items():
+            if not ag.global_critic or vb is None:
+                vb = ag._values((critic_b,))
+            self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
+        put(buf.last_val, self._row_f[2])
+        acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
+        self.complete_len.copy_(torch.where(episode_over, (ti + 1).expand(N), self.complete_len))
+        if epoch_ended:
+            env.set_epoch_end()
+        self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
+        obs_r, *_ = env.reset(cut)
+        self.obs.copy_(obs_r)
+        if self.predictor is not None:
+            self.predictor.reset(mask=cut)                              # hidden = ac.reset_hidden() (test_cnn/train.py:770)
+        self.ep_ret.masked_fill_(cut.unsqueeze(1), 0.0)
+        self.steps_in_ep.masked_fill_(cut, 0)
+        ti.add_(1)
+
+    @torch.no_grad()
     def collect(self) -> Dict[str, torch.Tensor]:
         if self.obs is None:
             self.start()
-        env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
-        dev = env.device
-        acc = EpochStats(A, dev)
+        T = self.T
+        self._acc.zero_()
         self.complete_len.zero_()
-        for t in range(T):
-            critic, cells, pcells = self._round()
-            self.shared[t] = critic
-            self.cells[t] = cells
-            self.pcells[t] = pcells
-            env.action_uniforms(self._u)
-            v_shared = None
-            for a, ag in self.agents.items():
-                act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
-                if not ag.global_critic or v_shared is None:      # one evaluation serves every owner of a global critic
-                    v_shared = ag._values((critic,))
-                buf.act[t, :, a] = act
-                buf.logp[t, :, a] = logp
-                buf.val[t, :, a] = v_shared
-                self._act8[:, a] = act.to(torch.int8)
-            buf.obs[t] = self.obs
-            next_obs, rew, team, done, info = env.step(self._act8)
-            r_used = team.unsqueeze(1).expand(N, A) if self.team_reward else rew
-            buf.rew[t] = r_used
-            self.ep_ret += r_used
-            self.steps_in_ep += 1
-            terminal = done.bool().any(dim=1)
-            acc.step(info["out_of_bounds"], done)
-            timeout = self.steps_in_ep == L
-            episode_over = terminal | timeout
-            epoch_ended = t == T - 1
-            cut = episode_over | epoch_ended
-            boot = timeout | epoch_ended
-            buf.cut[t] = cut.unsqueeze(1).to(torch.uint8).expand(N, A)
-            self.obs = next_obs.clone()
-            # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480);
-            # the maps of those envs see the final observation a second time, exactly as in the reference
-            critic_b, _, _ = self._round(mask=boot & cut)
-            vb = None
-            for a, ag in self.agents.items():
-                if not ag.global_critic or vb is None:
-                    vb = ag._values((critic_b,))
-                buf.last_val[t, :, a] = torch.where((boot & cut).bool(), vb, torch.zeros_like(vb))
-            acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
-            self.complete_len = torch.where(episode_over, torch.full_like(self.complete_len, t + 1), self.complete_len)
-            if epoch_ended:
-                env.set_epoch_end()
-            self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
-            obs_r, *_ = env.reset(cut)
-            self.obs = obs_r.clone()
-            if self.predictor is not None:
-                self.predictor.reset(mask=cut)                              # hidden = ac.reset_hidden() (test_cnn/train.py:770)
-            self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
-            self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
-        buf.finish(self.agents[0].gamma, self.agents[0].lam)
-        return acc.result()
+        self._t.zero_()
+        if self.use_graph and self._graph is None and T > 1:
+            # lazy library initialisation (rocBLAS handles / workspaces) must not fall into the capture: evaluate the
+            # networks once on the current maps (pure functions, no collector state changes), then record the step
+            side = torch.cuda.Stream(device=self.env.device)
+            side.wait_stream(torch.cuda.current_stream(self.env.device))
+            with torch.cuda.stream(side):
+                critic = self.maps.shared_maps()
+                cells, pcells = self.maps.field("cell").long(), self.maps.field("pred_cell").long()
+                for a, ag in self.agents.items():
+                    ag.act((critic, cells, pcells, a), self._u[:, a]); ag._values((critic,))
+                if self.predictor is not None:
+                    self.predictor._packed()
+            torch.cuda.current_stream(self.env.device).wait_stream(side)
+            torch.cuda.synchronize(self.env.device)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._step(False)
+        for t in range(T - 1):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step(False)
+        self._step(True)
+        self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return self._acc.result()
 
     def update(self) -> Dict[int, UpdateResult]:
         buf, T, N = self.buf, self.T, self.N

@@ -329,3 +329,31 @@ def test_cnn_train_entry_point_individual_critics(A):
         rows = sim.loggers[i].rows
         assert len(rows) == 2 and np.isfinite(rows[1]["loss_policy"]) and np.isfinite(rows[1]["loss_critic"])
         assert any(not torch.equal(a, b) for a, b in zip(before[i], critics[i].parameters()))     # each critic was trained
+
+
+def test_cnn_collector_graph_replay_equals_eager_steps():
+    """The captured lock-step (one HIP graph replayed T - 1 times per epoch) writes exactly what the eager loop writes: every
+    buffer, two epochs (the second one replays the graph captured in the first)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L = 32, 2, 24, 7
+
+    def run(use_graph):
+        torch.manual_seed(8)
+        env = RadSearchVec(N, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=SEED, env_id_base=32)
+        gc = CNNCritic().cuda()
+        agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=torch.optim.Adam(gc.parameters(), lr=1e-3)) for i in range(A)}
+        col = CNNCollector(env, agents, T, L, global_critic_flag=True, use_graph=use_graph)
+        out = []
+        for _ in range(2):
+            st = col.collect()
+            out.append({**{k: getattr(col.buf, k).clone() for k in ("obs", "act", "rew", "val", "logp", "last_val", "cut", "adv", "ret")},
+                        "shared": col.shared.clone(), "cells": col.cells.clone(), "pcells": col.pcells.clone(),
+                        "complete_len": col.complete_len.clone(), **{"stat_" + k: v.clone() for k, v in st.items()}})
+        assert (col._graph is not None) == use_graph
+        return out
+    g, e = run(True), run(False)
+    for ep in range(2):
+        for k in e[ep]:
+            assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
