@@ -225,7 +225,12 @@ typedef struct rs_ppo_batch {
 } rs_ppo_batch;
 
 size_t rs_ppo_grad_workspace_bytes(void);
-/* stop_flag (device int32, may be NULL): when non-zero at launch the call is a no-op (early stop already hit). */
+/* stop_flag (device int32, may be NULL): when non-zero at launch the call is a no-op (early stop already hit).
+ * grads: float32 [RS_PPO_GRAD_FLOATS] = the 10441 gradients (actor w1 b1 w2 b2 w3 b3, critic ...) followed by the five
+ * statistics once more as float32 (hi, lo) pairs (stats[q] = hi + lo) and zero padding: under data parallelism ONE
+ * all-reduce (SUM) of this buffer is the reference's mpi_avg_grads + mpi_avg(kl) (ppo.py:1250-1256). */
+#define RS_PPO_STATS_TAIL 16
+#define RS_PPO_GRAD_FLOATS (10441 + RS_PPO_STATS_TAIL)
 int rs_ppo_grad(const rs_mlp_params* actor, const rs_mlp_params* critic, const rs_ppo_batch* batch, float* grads,
                 double* stats, void* workspace, const int32_t* stop_flag, rs_stream_t stream);
 
@@ -243,7 +248,8 @@ typedef struct rs_update_state {
  *   if state->stopped: nothing.  else iters += 1, last_stats = stats;
  *   if stats[0] (approx_kl, already reduced over ranks) < kl_threshold: Adam step (torch.optim.Adam
  *   semantics, betas (0.9, 0.999), eps 1e-8) on all 12 tensors with `grads`; else stopped = 1.
- * actor/critic point at the LIVE parameter tensors (updated in place); m, v: float32 [10441]. */
+ * actor/critic point at the LIVE parameter tensors (updated in place); m, v: float32 [10441].
+ * stats == NULL: take the statistics from the (hi, lo) pairs behind the gradients (the all-reduced bucket). */
 int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
                  const double* stats, rs_update_state* state, float lr, float kl_threshold, rs_stream_t stream);
 

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(1024) rs_ppo_reduce_kernel(const float* __rest
     if (stop && *stop) {
         // early stop already hit: the gradient kernels were no-ops.  Publish zeros so that the data-parallel all-reduce that
         // follows every iteration (the host does not know the stop state) keeps summing finite, idempotent values.
-        if (grp == 0 && p < NA + NC) grads[p] = 0.0f;
+        if (grp == 0 && p < NA + NC + RS_PPO_STATS_TAIL) grads[p] = 0.0f;
         if (blockIdx.x == 0 && threadIdx.x < 5) stats[threadIdx.x] = 0.0;
         return;
     }
@@ -132,8 +132,16 @@ __global__ void __launch_bounds__(1024) rs_ppo_reduce_kernel(const float* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double t[5];
         for (int q = 0; q < 5; ++q) { double v = 0; for (int i = 0; i < 64; ++i) v += spart[q][i]; t[q] = v; }
-        stats[0] = t[0]; stats[1] = t[1]; stats[2] = t[2]; stats[3] = t[3];
-        stats[4] = -(t[4] - (double)vf * t[3] + (double)alpha * t[1]);       // ppo.py:1221-1225
+        t[4] = -(t[4] - (double)vf * t[3] + (double)alpha * t[1]);           // ppo.py:1221-1225
+        // the statistics also ride at the end of the gradient bucket as float32 (hi, lo) pairs, so that ONE all-reduce of the
+        // bucket exchanges gradients and statistics between the ranks (xGMI all-reduces of this size are latency bound)
+        for (int q = 0; q < 5; ++q) {
+            stats[q] = t[q];
+            const float hi = (float)t[q];
+            grads[NA + NC + 2 * q] = hi;
+            grads[NA + NC + 2 * q + 1] = (float)(t[q] - (double)hi);
+        }
+        for (int q = 10; q < RS_PPO_STATS_TAIL; ++q) grads[NA + NC + q] = 0.0f;
     }
 }
 
@@ -146,7 +154,9 @@ __global__ void __launch_bounds__(256) rs_adam_apply_kernel(RsParamSeg S, const 
                                                             float* __restrict__ v, const double* __restrict__ stats,
                                                             const rs_update_state* __restrict__ st, float lr, float thr) {
     if (st->stopped) return;
-    if (!(stats[0] < (double)thr)) return;                       // kl >= 1.5 * target_kl: no step (ppo.py:1252-1261)
+    // stats == nullptr: the (all-reduced) statistics are the (hi, lo) pairs behind the gradients
+    const double kl = stats ? stats[0] : (double)grads[S.off[12]] + (double)grads[S.off[12] + 1];
+    if (!(kl < (double)thr)) return;                             // kl >= 1.5 * target_kl: no step (ppo.py:1252-1261)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S.off[12]) return;
     int seg = 0;
@@ -165,11 +175,11 @@ __global__ void __launch_bounds__(256) rs_adam_apply_kernel(RsParamSeg S, const 
     *p = *p - step_size * (mi / denom);
 }
 
-__global__ void rs_adam_commit_kernel(const double* __restrict__ stats, rs_update_state* st, float thr) {
+__global__ void rs_adam_commit_kernel(const double* __restrict__ stats, const float* __restrict__ tail, rs_update_state* st, float thr) {
     if (st->stopped) return;
     st->iters += 1;
-    for (int q = 0; q < 5; ++q) st->last_stats[q] = stats[q];
-    if (stats[0] < (double)thr) st->adam_step += 1; else st->stopped = 1;
+    for (int q = 0; q < 5; ++q) st->last_stats[q] = stats ? stats[q] : (double)tail[2 * q] + (double)tail[2 * q + 1];
+    if (st->last_stats[0] < (double)thr) st->adam_step += 1; else st->stopped = 1;
 }
 
 extern "C" {
@@ -198,7 +208,7 @@ size_t rs_ppo_grad_workspace_bytes(void) {
 
 int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const float* grads, float* m, float* v,
                  const double* stats, rs_update_state* state, float lr, float kl_threshold, rs_stream_t stream) {
-    if (!actor || !critic || !grads || !m || !v || !stats || !state) return RS_ERR_INVALID_ARG;
+    if (!actor || !critic || !grads || !m || !v || !state) return RS_ERR_INVALID_ARG;
     RsParamSeg S;
     const float* ptrs[12] = {actor->w1, actor->b1, actor->w2, actor->b2, actor->w3, actor->b3,
                              critic->w1, critic->b1, critic->w2, critic->b2, critic->w3, critic->b3};
@@ -208,7 +218,7 @@ int rs_adam_step(const rs_mlp_params* actor, const rs_mlp_params* critic, const 
     S.off[12] = o;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(rs_adam_apply_kernel, dim3((o + 255) / 256), dim3(256), 0, s, S, grads, m, v, stats, state, lr, kl_threshold);
-    hipLaunchKernelGGL(rs_adam_commit_kernel, dim3(1), dim3(1), 0, s, stats, state, kl_threshold);
+    hipLaunchKernelGGL(rs_adam_commit_kernel, dim3(1), dim3(1), 0, s, stats, grads + o, state, kl_threshold);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

@@ -94,8 +94,10 @@ class FusedPPOGrad:
         dev = next(ac.parameters()).device
         # one flat float32 bucket = all gradients (the data-parallel exchange reduces it in ONE collective); the five
         # loss statistics stay float64 end to end so the KL early-stop decision is bit-identical for 1 and N ranks
-        self.grads = torch.zeros(N_PARAMS, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(N_PARAMS + 16, dtype=torch.float32, device=dev)     # RS_PPO_GRAD_FLOATS: gradients + (hi, lo) statistics
+        self.grads = self.bucket[:N_PARAMS]
         self.stats = torch.zeros(5, dtype=torch.float64, device=dev)
+        self.stats_from_bucket = False
         self.ws = torch.empty(self.lib.rs_ppo_grad_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
         self._ws_ptr = self.ws.data_ptr() + (-self.ws.data_ptr()) % 256
         # views of the flat gradient in the parameter order of the C ABI
@@ -118,8 +120,8 @@ class FusedPPOGrad:
     def adam_step(self, lr: float, kl_threshold: float) -> None:
         import ctypes as C
         pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
-        _lib.check(self.lib.rs_adam_step(C.byref(pa), C.byref(pc), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                         self.stats.data_ptr(), self.state.data_ptr(), lr, kl_threshold,
+        _lib.check(self.lib.rs_adam_step(C.byref(pa), C.byref(pc), self.bucket.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         None if self.stats_from_bucket else self.stats.data_ptr(), self.state.data_ptr(), lr, kl_threshold,
                                          torch.cuda.current_stream(self.grads.device).cuda_stream), "rs_adam_step")
 
     def read_state(self):
@@ -134,22 +136,24 @@ class FusedPPOGrad:
         for t in (X, adv, ret, logp_old, w):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert act.dtype == torch.int64 and act.is_contiguous()
+        self.stats_from_bucket = False                 # set by allreduce(): the reduced statistics then live in the bucket's tail
         b = _lib.RsPpoBatch(X.data_ptr(), act.data_ptr(), adv.data_ptr(), ret.data_ptr(), logp_old.data_ptr(), w.data_ptr(),
                             X.shape[0], clip_ratio, alpha, vf_coef)
         pa, pc = mlp_params(self.ac.actor), mlp_params(self.ac.critic)
         with _lib.timed("rs_ppo_grad"):
-            _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.grads.data_ptr(), self.stats.data_ptr(),
+            _lib.check(self.lib.rs_ppo_grad(C.byref(pa), C.byref(pc), C.byref(b), self.bucket.data_ptr(), self.stats.data_ptr(),
                                             self._ws_ptr, (self.state.data_ptr() + 4) if use_stop_flag else None,
                                             torch.cuda.current_stream(X.device).cuda_stream), "rs_ppo_grad")
         return self.stats, self.grads
 
     def allreduce(self) -> None:
-        """mpi_avg_grads (ppo.py:1256) + mpi_avg(kl) (:1250): one RCCL all-reduce of the flat gradient bucket and one of
-        the five float64 statistics per Adam step (xGMI all-reduces of this size are latency bound: the count matters,
-        not the bytes).  The loss weights already carry 1/(global env count): SUM over ranks = the reference's average.
-        After the KL early stop rs_ppo_grad publishes zeros, so the remaining (no-op) iterations reduce zeros."""
-        dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
-        dist.all_reduce(self.stats, op=dist.ReduceOp.SUM)
+        """mpi_avg_grads (ppo.py:1256) + mpi_avg(kl) (:1250) as ONE RCCL all-reduce per Adam step: the bucket holds the
+        gradients and, behind them, the five statistics as float32 (hi, lo) pairs written by the reduce kernel (xGMI
+        all-reduces of this size are latency bound: the count matters, not the bytes).  rs_adam_step then takes the
+        statistics from the bucket.  The loss weights already carry 1/(global env count): SUM over ranks = the reference's
+        average.  After the KL early stop rs_ppo_grad publishes zeros, so the remaining (no-op) iterations reduce zeros."""
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        self.stats_from_bucket = True
 
     def assign_grads(self) -> None:
         for p, g in self.views:

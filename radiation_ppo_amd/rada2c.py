@@ -27,6 +27,7 @@ Deviations, all forced by batching and stated here: (i) update_model clips the g
 reference clips per rank, then averages, ppo.py:1137-1141); (ii) LocLoss is the RMS over all samples (the reference reports the
 loop's last episode, :1274); (iii) several agents are independent copies, each fed its own observation row.
 """
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
@@ -222,7 +223,7 @@ class RNNAgentPPO:
                  actor_critic_args: Optional[Dict[str, Any]] = None, train_pi_iters: int = 40, train_pfgru_iters: int = 15,
                  actor_learning_rate: float = 3e-4, pfgru_learning_rate: float = 5e-3, gamma: float = 0.99, alpha: float = 0.1,
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, bp_args: Optional[Any] = None,
-                 env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 4096,
+                 env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 8192,
                  GlobalCriticOptimizer=None, **unused: Any):
         if actor_critic_architecture != "rnn":
             raise ValueError("Unsupported Neural Network type requested")
@@ -279,6 +280,31 @@ class RNNAgentPPO:
             if want_particles:
                 parts.append(cell.hid_obs(h))                                     # particle_pred[zz] (ppo.py:1079)
         return torch.stack(locs), (torch.stack(parts) if want_particles else None)
+
+    def _pfgru_pass_hip(self, X: torch.Tensor, draws: "HashDraws") -> torch.Tensor:
+        """The no-grad PFGRU pass of grad_step (:555-558) on K11: X [L, E, 11] -> loc [L, E, 2].  Particle sets start from the
+        reset kernel's hash draws and are carried; the draw keys are the chunk's episode keys."""
+        from .pfgru import pack_weights
+        lib = _lib.load()
+        L, E = X.shape[0], X.shape[1]
+        dev = X.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        h = torch.empty(1, E, 40, 24, dtype=torch.float32, device=dev)
+        p = torch.empty(1, E, 40, dtype=torch.float32, device=dev)
+        base = draws.k.contiguous().view(1, E)
+        episode = torch.ones(E, dtype=torch.int64, device=dev)
+        calls = torch.zeros(E, dtype=torch.int64, device=dev)
+        wts = pack_weights([self.agent.model])
+        loc = torch.empty(L, E, 2, dtype=torch.float32, device=dev)
+        _lib.check(lib.rs_pfgru_reset(h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(), None, E, 1, st),
+                   "rs_pfgru_reset")
+        Xc = X.contiguous()
+        for t in range(L):
+            _lib.check(lib.rs_pfgru_step(wts.data_ptr(), Xc[t].data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(),
+                                         calls.data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), E, 1, st),
+                       "rs_pfgru_step")
+            calls.add_(1)
+        return loc
 
     def model_loss(self, B: EpisodeBatch, sl: slice, draws) -> torch.Tensor:
         """Sum over the chunk's episodes of w_ep x total_loss (ppo.py:1062-1128)."""
@@ -337,14 +363,17 @@ class RNNAgentPPO:
         w = B.w[:, sl]
         L, E = X.shape[0], X.shape[1]
         with torch.no_grad():
-            loc, _ = self._pfgru_pass(X[..., :3], draws, False)
+            if isinstance(draws, HashDraws) and X.is_cuda:
+                loc = self._pfgru_pass_hip(X, draws)          # K11 with carried particle sets: one launch per step
+            else:
+                loc, _ = self._pfgru_pass(X[..., :3], draws, False)
         h = draws.gru_h0() if hasattr(draws, "gru_h0") else ac.gru_h0(draws.gru_h0_u())
-        lg, vs = [], []
-        for t in range(L):
-            logits, val, h = ac.policy_step(X[t], loc[t], h)
-            lg.append(logits); vs.append(val)
-        logp_all = torch.log_softmax(torch.stack(lg), dim=-1)                      # Categorical(logits=...) (:443-446)
-        val = torch.stack(vs)
+        # the GRU over the whole (padded) episode batch in one sequence call, as grad_step does (:564): states past an episode's
+        # end are computed and never used (weight 0)
+        hs, _ = ac.pi.logits_net.v_net.seq_model(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
+        logits, val = ac.heads(hs.reshape(L * E, -1))
+        logp_all = torch.log_softmax(logits.view(L, E, -1), dim=-1)               # Categorical(logits=...) (:443-446)
+        val = val.view(L, E)
         logp = logp_all.gather(-1, B.act[:, sl].unsqueeze(-1)).squeeze(-1)
         adv, ret, logp_old = B.adv[:, sl], B.ret[:, sl], B.logp[:, sl]
         ratio = torch.exp(logp - logp_old)

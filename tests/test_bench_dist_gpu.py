@@ -66,9 +66,9 @@ def test_data_parallel_equals_single_process(tmp_path):
 
 
 def test_data_parallel_kl_stop_in_the_middle_of_the_loop(tmp_path):
-    """The KL early stop (ppo.py:1250-1261) hits mid-loop: both world sizes stop at the same iteration (the five float64
-    statistics are all-reduced in float64, so the decision does not depend on the rank count), and the remaining no-op
-    iterations leave zeros -- not a growing sum -- in the all-reduced gradient bucket and statistics."""
+    """The KL early stop (ppo.py:1250-1261) hits mid-loop: both world sizes stop at the same iteration (the five statistics
+    travel with the gradients as float32 (hi, lo) pairs of their float64 values: one all-reduce per Adam step, ~1e-14 relative
+    loss), and the remaining no-op iterations leave zeros -- not a growing sum -- in the all-reduced bucket and statistics."""
     import torch
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     worker = os.path.join(ROOT, "tests", "_dp_worker.py")
