@@ -101,20 +101,43 @@ struct RsDrawSeq {
     }
 };
 
+// The rare branches of the sampler are real function calls (not inlined): their float64 library code (exp, log, lgamma)
+// and constants otherwise sit in the register budget of EVERY env kernel -- the obstacle step kernel spilled 64-bit
+// addresses to scratch at 256 VGPRs and paid a scratch round trip in nearly every phase (profiles/r02_env_step_phase_cycles.txt).
+__device__ __noinline__ int64_t rs_poisson_small(double lam, uint32_t t, uint32_t episode, uint32_t stream, uint32_t k0, uint32_t k1) {
+    double enlam = exp(-lam);
+    int64_t x = 0;
+    double prod = 1.0;
+    for (uint32_t i = 0;; ++i) {
+        u32x4 o = philox4x32_10(i, t, episode, stream, k0, k1);
+        prod *= u53(o.x, o.y);
+        if (prod > enlam) x += 1; else return x;
+    }
+}
+// PTRS slow path (~10 % of the draws).  Hormann's test  log(V) + log(invalpha) - log(a/us^2 + b)  <=
+// -lam + k log(lam) - lgamma(k+1)  evaluated with ONE log on the left and, for x = k+1 >= 10, the
+// Stirling series of lgamma on the right (truncation error < 1e-12 at x = 10):
+//   rhs = k log(lam/x) - log(x)/2 - lam + x - log(2 pi)/2 - (1/(12x) - 1/(360x^3) + 1/(1260x^5) - 1/(1680x^7))
+__device__ __noinline__ bool rs_ptrs_slow_accept(double v, double us, double k, double lam, double a, double b) {
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double lhs = log(v * invalpha / (a / (us * us) + b));
+    const double x = k + 1.0;
+    double rhs;
+    if (x >= 10.0) {
+        const double xi = 1.0 / x, xi2 = xi * xi;
+        const double ser = xi * (0.083333333333333333 - xi2 * (0.0027777777777777778 - xi2 * (0.00079365079365079365 - xi2 * 0.00059523809523809524)));
+        rhs = k * log(lam / x) - 0.5 * log(x) - lam + x - 0.91893853320467274 - ser;
+    } else {
+        rhs = -lam + k * log(lam) - lgamma(x);
+    }
+    return lhs <= rhs;
+}
+
 // Poisson(lam): Hormann PTRS for lam >= 10 (what numpy's Generator.poisson does there), the
 // multiplication method below 10.  Uniform pair i of the draw comes from Philox counter word 0 = i.
 __device__ __forceinline__ int64_t rs_poisson(double lam, uint32_t t, uint32_t episode, uint32_t stream, uint32_t k0, uint32_t k1) {
     if (lam == 0.0) return 0;
-    if (lam < 10.0) {
-        double enlam = exp(-lam);
-        int64_t x = 0;
-        double prod = 1.0;
-        for (uint32_t i = 0;; ++i) {
-            u32x4 o = philox4x32_10(i, t, episode, stream, k0, k1);
-            prod *= u53(o.x, o.y);
-            if (prod > enlam) x += 1; else return x;
-        }
-    }
+    if (lam < 10.0) return rs_poisson_small(lam, t, episode, stream, k0, k1);
     double slam = sqrt(lam);
     double b = 0.931 + 2.53 * slam;
     double a = -0.059 + 0.02483 * b;
@@ -128,22 +151,7 @@ __device__ __forceinline__ int64_t rs_poisson(double lam, uint32_t t, uint32_t e
         double k = floor((2.0 * a / us + b) * u + lam + 0.43);
         if (us >= 0.07 && v <= vr) return (int64_t)k;
         if (k < 0.0 || (us < 0.013 && v > us)) continue;
-        // slow path (~10 % of the draws).  Hormann's test  log(V) + log(invalpha) - log(a/us^2 + b)  <=
-        // -lam + k log(lam) - lgamma(k+1)  evaluated with ONE log on the left and, for x = k+1 >= 10, the
-        // Stirling series of lgamma on the right (truncation error < 1e-12 at x = 10):
-        //   rhs = k log(lam/x) - log(x)/2 - lam + x - log(2 pi)/2 - (1/(12x) - 1/(360x^3) + 1/(1260x^5) - 1/(1680x^7))
-        const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-        const double lhs = log(v * invalpha / (a / (us * us) + b));
-        const double x = k + 1.0;
-        double rhs;
-        if (x >= 10.0) {
-            const double xi = 1.0 / x, xi2 = xi * xi;
-            const double ser = xi * (0.083333333333333333 - xi2 * (0.0027777777777777778 - xi2 * (0.00079365079365079365 - xi2 * 0.00059523809523809524)));
-            rhs = k * log(lam / x) - 0.5 * log(x) - lam + x - 0.91893853320467274 - ser;
-        } else {
-            rhs = -lam + k * log(lam) - lgamma(x);
-        }
-        if (lhs <= rhs) return (int64_t)k;
+        if (rs_ptrs_slow_accept(v, us, k, lam, a, b)) return (int64_t)k;
     }
 }
 
@@ -403,6 +411,28 @@ __device__ __forceinline__ bool rs_pt_in_closed_eps(double qx, double qy, int x0
     return sqrt(dx * dx + dy * dy) <= 0.0000001;
 }
 
+// correct_coords (:1263-1306): walk the eight probe directions outwards in 0.1 cm steps until one of them touches the
+// rectangle; returns the bit mask of the touching directions (0 with *capped when the iteration cap was hit).  Rare (a
+// detector in a rectangle corner region): kept out of line for the register budget of the env kernels.
+__device__ __noinline__ uint32_t rs_correct_walk(int px, int py, int x0, int y0, int x1, int y1, int* capped) {
+    double qx[8], qy[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { qx[a] = (double)px; qy[a] = (double)py; }
+    uint32_t chk = 0;
+    int it = 0;
+    while (chk == 0) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            int cx, cy; rs_dir_coeff(a, cx, cy);
+            qx[a] = qx[a] + (double)cx * 0.1;
+            qy[a] = qy[a] + (double)cy * 0.1;
+            if (rs_pt_in_closed_eps(qx[a], qy[a], x0, y0, x1, y1)) chk |= 1u << a;
+        }
+        if (++it >= RS_CORRECT_CAP) { *capped = 1; break; }
+    }
+    return chk;
+}
+
 // obstruction_sensors (:1172-1261) + correct_coords (:1263-1306).  Writes the 8 readings (float64
 // values rounded once to float32, as the PPO buffer does) to out[0..7] (an LDS row).
 template <bool HAS_OBS, int CN = 1>
@@ -479,21 +509,9 @@ __device__ __forceinline__ void rs_sensors(const RsParams& P, const RsGeo& g, in
                 if (gt) best = k;
             }
             int x0, y0, x1, y1; g.rect(best, x0, y0, x1, y1);
-            double qx[8], qy[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) { qx[a] = (double)px; qy[a] = (double)py; }
-            uint32_t chk = 0;
-            int it = 0;
-            while (chk == 0) {
-#pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    int cx, cy; rs_dir_coeff(a, cx, cy);
-                    qx[a] = qx[a] + (double)cx * 0.1;
-                    qy[a] = qy[a] + (double)cy * 0.1;
-                    if (rs_pt_in_closed_eps(qx[a], qy[a], x0, y0, x1, y1)) chk |= 1u << a;
-                }
-                if (++it >= RS_CORRECT_CAP) { err |= RS_ENVERR_CORRECT_CAP; break; }
-            }
+            int capped = 0;
+            const uint32_t chk = rs_correct_walk(px, py, x0, y0, x1, y1, &capped);
+            if (capped) err |= RS_ENVERR_CORRECT_CAP;
 #pragma unroll
             for (int i = 0; i < 8; ++i) d8[i] = 0.0;
             if (__popc(chk) >= 4) {
@@ -535,6 +553,24 @@ struct RsOut {
 // RadSearch.step for env n (one lane).  act_of(a) returns agent a's action (0..8) or RS_ACT_NONE.
 // Mirrors step :443-728 / agent_step :460-613; agents are processed in id order because `done`, the
 // team reward and the collision rule are order dependent.
+// Diagnostic build only (-DRS_STEP_STAMPS, scripts/step_stamps.py): wave-level s_memtime stamps at the phase boundaries of the
+// env step, added to a table nothing else reads.  The product build contains none of it.
+#ifdef RS_STEP_STAMPS
+static __device__ unsigned long long rs_step_stamp_table[16];
+__device__ __forceinline__ unsigned long long rs_es_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define RS_ESTAMP_DECL unsigned long long es_last = rs_es_now();
+#define RS_ESTAMP(i) do { const unsigned long long t_ = rs_es_now(); \
+                          if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&rs_step_stamp_table[i], t_ - es_last); \
+                          es_last = rs_es_now(); } while (0)
+#else
+#define RS_ESTAMP_DECL
+#define RS_ESTAMP(i) do {} while (0)
+#endif
+
 // CN > 1: the cooperative form (see rs_grp_any): lanes cj = 0..CN-1 of a group call this with the same n, g, actions and O.
 // Every lane of the group stores the (identical) results: duplicate addresses inside one store instruction cost nothing,
 // and each lane's later loads of the env state are then ordered after its OWN stores, which the language guarantees.
@@ -542,6 +578,7 @@ template <bool HAS_OBS, int CN = 1, typename ActFn>
 __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo& g, int n, ActFn act_of, const RsOut& O,
                                                  bool no_collision_rule = false, int cj = 0) {
     const int N = P.N, A = P.A;
+    RS_ESTAMP_DECL
     const int sx = P.src_x[n], sy = P.src_y[n];
     const int intensity = P.intensity[n], bkg = P.bkg[n];
     int iter_count = P.iter_count[n];
@@ -570,6 +607,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
 
     double max_reward = 0.0;
     bool have_max = false;
+    RS_ESTAMP(0);                                            // state loads, collision proposals
     for (int a = 0; a < A; ++a) {
         const size_t ia = (size_t)a * N + n;
         int act = act_of(a);
@@ -599,6 +637,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
                 if (!roll_back) { x = tx; y = ty; px = tx; py = ty; moved = true; }
             }
         }
+        RS_ESTAMP(1);                                        // take_action, in_obstruction
         // ---- distances, line of sight, measurement, reward :486-567
         double euc = rs_dist_i(x, y, sx, sy);               // == the stale euc_dist when stalled (position unchanged)
         double reward;
@@ -608,12 +647,14 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
         if (moved) sp = (HAS_OBS && g.n > 0) ? rs_shortest_path<CN>(g, P.dsrc, N, n, sx, sy, x, y, cj) : euc;
 #endif
         if (HAS_OBS && !(sp < INFINITY)) err |= RS_ENVERR_NO_PATH;
+        RS_ESTAMP(2);                                        // shortest path
 #if defined(RS_ABL) && RS_ABL == 2
         bool inter = false;
 #else
         bool inter = (HAS_OBS && g.n > 0) ? rs_is_intersect<CN>(g, px, py, sx, sy, euc, sp, cj) : false;
 #endif
         fl = (uint8_t)((fl & ~RS_AF_INTERSECT) | (inter ? RS_AF_INTERSECT : 0));
+        RS_ESTAMP(3);                                        // is_intersect
         double lam;
         if (inter) lam = (double)bkg;
         else {
@@ -622,6 +663,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
             lam = (P.falloff ? ((double)intensity / (r * r)) : ((double)intensity / r)) + (double)bkg;
         }
         int64_t meas = rs_poisson(lam, t, episode, RS_STREAM_STEP + (uint32_t)a, k0, k1);
+        RS_ESTAMP(4);                                        // Poisson measurement
         if (moved) {
             if (sp < 110.0) { reward = 0.1; done = true; }
             else if (sp < prev) { reward = 0.1; prev = sp; }
@@ -636,11 +678,13 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
         row[0] = (float)(double)meas;
         row[1] = (float)(((double)x + 0.0) * P.scale);
         row[2] = (float)(((double)y + 0.0) * P.scale);
+        RS_ESTAMP(5);                                        // reward, observation head
         if ((HAS_OBS && g.n > 0) || P.enforce) rs_sensors<HAS_OBS, CN>(P, g, px, py, row + 3, err, cj);
         else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) row[3 + i] = 0.0f;
         }
+        RS_ESTAMP(6);                                        // obstruction sensors
         // ---- team reward with the falsy-reset quirk :662-665
         if (!have_max || max_reward == 0.0) { max_reward = reward; have_max = true; }
         else if (max_reward < reward) max_reward = reward;
@@ -659,6 +703,7 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
     P.iter_count[n] = iter_count + 1;
     P.tstep[n] = t + 1;
     if (err) P.err[n] |= err;
+    RS_ESTAMP(7);                                            // write back
 }
 
 // ------------------------------------------------------------------------------------------------

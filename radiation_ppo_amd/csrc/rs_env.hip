@@ -503,4 +503,17 @@ int rs_gae(const float* rew, const float* val, const uint8_t* cut, const float* 
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
+#ifdef RS_STEP_STAMPS
+// diagnostic build only: read (and optionally clear) the phase-cycle table of the env step; out[16]
+int rs_debug_step_stamps(unsigned long long* out, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return RS_ERR_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rs_step_stamp_table), sizeof(unsigned long long) * 16) != hipSuccess) return RS_ERR_HIP;
+    if (clear) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rs_step_stamp_table), z, sizeof(z)) != hipSuccess) return RS_ERR_HIP;
+    }
+    return RS_OK;
+}
+#endif
+
 }  // extern "C"
