@@ -427,9 +427,7 @@ int rs_reset(rs_handle* h, const uint8_t* mask, float* obs, float* reward, float
         hipLaunchKernelGGL(rs_geom_kernel, dim3((P.G + 63) / 64), dim3(64), RS_MAX_VERT * RS_WAVE * 4, s, P, mask);
     }
     size_t lds = tile_bytes(P.A) + (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
-    static const bool one_lane = getenv("RS_STEP_ONE_LANE") != nullptr;       // A/B switch: the one-env-per-lane obstacle kernels
-    if (has_obs && !one_lane) hipLaunchKernelGGL(rs_reset4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
-    else if (has_obs) hipLaunchKernelGGL(rs_reset_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
+    if (has_obs) hipLaunchKernelGGL(rs_reset4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_reset_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, mask, obs, make_out(reward, team, done, info));
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
@@ -456,9 +454,7 @@ int rs_step(rs_handle* h, const int8_t* actions, float* obs, float* reward, floa
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RsParams& P = h->P;
     size_t lds = tile_bytes(P.A) + (P.obstruction_count != 0 ? RS_MAX_VERT * RS_WAVE * 4 : 0);
-    static const bool one_lane = getenv("RS_STEP_ONE_LANE") != nullptr;       // A/B switch: the one-env-per-lane obstacle step
-    if (P.obstruction_count != 0 && !one_lane) hipLaunchKernelGGL(rs_step4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
-    else if (P.obstruction_count != 0) hipLaunchKernelGGL(rs_step_kernel<true>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
+    if (P.obstruction_count != 0) hipLaunchKernelGGL(rs_step4_kernel, dim3((P.N + 15) / 16), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
     else hipLaunchKernelGGL(rs_step_kernel<false>, dim3((P.N + 63) / 64), dim3(64), lds, s, P, actions, obs, make_out(reward, team, done, info));
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

@@ -1,5 +1,4 @@
-"""Obstacle env timing: rs_step (8192 envs, 1-5 rectangles; 4096 x 4 agents) and the fused rollout of config 3.
-RS_STEP_ONE_LANE=1 selects the one-env-per-lane step kernel for an A/B run."""
+"""Obstacle env timing: rs_step (8192 envs, 1-5 rectangles; 4096 x 4 agents) and the fused rollout of config 3."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
