@@ -228,8 +228,20 @@ __global__ void __launch_bounds__(64) rs_gae_kernel(const float* __restrict__ re
     const int t_hi = min(T, t_lo + chunk) - 1;
     if (t_lo >= T) return;
     // nearest cut at or after t_hi (none: the scan starts at T-1 from a zero state, as the serial scan does)
+    // sixteen rows per probe: the flags of a probe are independent loads (one latency), where a row-by-row search paid one
+    // HBM latency per step -- up to an episode length of them, which was most of this kernel's time
     int t_start = t_hi;
-    while (t_start < T - 1 && cut[(size_t)t_start * M + m] == 0) ++t_start;
+    for (;;) {
+        uint8_t cc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cc[u] = cut[(size_t)min(t_start + u, T - 1) * M + m];
+        int found = -1;
+#pragma unroll
+        for (int u = 15; u >= 0; --u)
+            if (cc[u] != 0 || t_start + u >= T - 1) found = u;
+        if (found >= 0) { t_start = min(t_start + found, T - 1); break; }
+        t_start += 16;
+    }
     double a_acc = 0.0, r_acc = 0.0, v_next = 0.0;
     float r8[RS_GAE_U], v8[RS_GAE_U], l8[RS_GAE_U], rn[RS_GAE_U], vn[RS_GAE_U], ln[RS_GAE_U];
     uint8_t c8[RS_GAE_U], cn[RS_GAE_U];
