@@ -144,6 +144,10 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     double ep_ret_sum = 0.0, ep_len_sum = 0.0, ep_ret_sq = 0.0;
     float ep_ret_max = -INFINITY, ep_ret_min = INFINITY;
     const uint32_t k0 = P.seed, k1 = P.env_id_base + (uint32_t)n;
+    // per-episode constants and the step counter the sampler's Philox counter needs are mirrored in registers (re-read after a
+    // reset only): a global load per lock-step is a full memory latency for the lone wave of a SIMD
+    uint32_t ep_key = P.episode[n] - 1u, t_key = P.tstep[n];
+    float srcx = (float)P.src_x[n], srcy = (float)P.src_y[n];
 
     float xo[RS_IN_PAD], xs[RS_IN_PAD];
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) se += __expf(lg[q] - mx);
             const float lse = __logf(se);
-            const uint32_t episode = P.episode[n] - 1u, tenv = P.tstep[n];
+            const uint32_t episode = ep_key, tenv = t_key;
             u32x4 ph = philox4x32_10(0u, tenv, episode, RS_STREAM_ACT, k0, k1);
             const float u = (float)(ph.x >> 8) * (1.0f / 16777216.0f);
             float cdf = 0.0f;
@@ -205,8 +209,8 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
             R.act[row] = (int64_t)a;
             R.logp[row] = logp;
             R.val[row] = v;
-            R.source_tar[row * 2 + 0] = (float)P.src_x[n];
-            R.source_tar[row * 2 + 1] = (float)P.src_y[n];
+            R.source_tar[row * 2 + 0] = srcx;
+            R.source_tar[row * 2 + 1] = srcy;
         }
         if (HAS_OBS) {
             const int a_env = __shfl(a, j);
@@ -221,6 +225,7 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
             R.rew[row] = r;
             ep_ret += r;
             steps += 1;
+            t_key += 1u;                                         // the env advanced its step counter (rs_env_step_lane)
             done_count += terminal ? 1 : 0;
             const bool timeout = steps == L;
             over = terminal || timeout;
@@ -265,6 +270,8 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
                 xo[0] = W.standardize(oraw[0]);
                 steps = 0;
                 ep_ret = 0.0f;
+                ep_key = P.episode[n] - 1u; t_key = P.tstep[n];  // new episode: new source, new Philox counters
+                srcx = (float)P.src_x[n]; srcy = (float)P.src_y[n];
             }
         }
         v = vb;
