@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long rs_k7_now() {
 #define RS_G2_WAVE_FLOATS ((64 + 32) * RS_T2 + RS_XRAW + RS_XSC + 64)
 
 __host__ __device__ constexpr int rs_grad2_lds_floats(int nout) {
-    return rs_mlp_lds_floats(nout) + 2 * 2 * 16 * 64 + 2 * 4 * 64 + 8 * RS_G2_WAVE_FLOATS;
+    return ((rs_mlp_lds_floats(nout) + 3) & ~3) + 2 * 2 * 16 * 64 + 2 * 4 * 64 + 8 * RS_G2_WAVE_FLOATS;
 }
 
 __device__ __forceinline__ void rs_stage32(float* T, const f32x16& v, int c, int h) {
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
     if (stop && *stop) return;
     RsMlpLds<NOUT> W;
     W.carve(smem_f);
-    float* w2tf = smem_f + rs_mlp_lds_floats(NOUT);     // [2 it][2 kt][16 r][64]: W2[32kt + kappa][32it + (l&31)]
+    float* w2tf = smem_f + ((rs_mlp_lds_floats(NOUT) + 3) & ~3);   // 16-byte aligned; [2 it][2 kt][4 r4][64 lanes][4]: W2[32kt + kappa(r, l>>5)][32it + (l&31)]
     float* w3tf = w2tf + 2 * 2 * 16 * 64;               // [2 it][4 s][64]:        W3[2s + (l>>5)][32it + (l&31)]
     // wave id as a SCALAR: the per-wave LDS bases below then live in SGPRs (and M0 for the LDS-DMA) instead of VGPRs
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,8 +72,12 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
     float* xsc = xraw + RS_XRAW;                               // [192]     the group's per-sample scalars (LDS-DMA target)
     float* dbl = xsc + RS_XSC;                                 // [64]      db2 accumulators of this wave
     W.fill(prm);
+    // W2 fragments for the matrix pipe, four consecutive k-steps per lane contiguous ([it][kt][r / 4][lane][r % 4]): one
+    // ds_read_b128 feeds four MFMAs (an LDS read instruction costs the wave ~13 issue cycles whatever its width).  The forward
+    // copy (W.w2f, filled by W.fill in the layout rs_policy_forward uses) is rewritten in the same form below.
     for (int i = threadIdx.x; i < 2 * 2 * 16 * 64; i += blockDim.x) {
-        int l = i & 63, r = (i >> 6) & 15, kt = (i >> 10) & 1, it = i >> 11;
+        const int ri = i & 3, l = (i >> 2) & 63, r4 = (i >> 8) & 3, kt = (i >> 10) & 1, it = i >> 11;
+        const int r = 4 * r4 + ri;
         w2tf[i] = prm.w2[(32 * kt + rs_kappa(r, l >> 5)) * RS_HID + 32 * it + (l & 31)];
     }
     for (int i = threadIdx.x; i < 2 * 4 * 64; i += blockDim.x) {
@@ -83,6 +87,11 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
     }
     dbl[lane] = 0.0f;
     __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 2 * 16 * 64; i += blockDim.x) {
+        const int ri = i & 3, l = (i >> 2) & 63, r4 = (i >> 8) & 3, kt = (i >> 10) & 1, it = i >> 11;
+        const int r = 4 * r4 + ri;
+        W.w2f[i] = RS_TANH_PRESCALE * prm.w2[(32 * it + (l & 31)) * RS_HID + 32 * kt + rs_kappa(r, l >> 5)];
+    }
     // layer-1 fragments with the bias in the padded input column k = 11 (k-step 5, upper lane half)
     float* w1b = W.w1f;
     for (int i = threadIdx.x; i < 2 * 32; i += blockDim.x) {
@@ -204,17 +213,24 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
         RS_STAMP(2);                                    // tanh 1 + bias loads
         {
             // both output tiles advance together: two independent accumulators per fragment pair
-            float a0 = W.w2f[((0 * 2 + 0) * 16 + 0) * 64 + lane], a1 = W.w2f[((1 * 2 + 0) * 16 + 0) * 64 + lane];
+            const float4* wq = reinterpret_cast<const float4*>(W.w2f) + lane;       // [(it * 2 + kt) * 4 + r4][64 lanes]
+            float4 a0 = wq[0], a1 = wq[(1 * 2 + 0) * 4 * 64];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int kt = q >> 4, r = q & 15;
-                float n0 = 0.f, n1 = 0.f;
-                if (q + 1 < 32) {
-                    n0 = W.w2f[((0 * 2 + ((q + 1) >> 4)) * 16 + ((q + 1) & 15)) * 64 + lane];
-                    n1 = W.w2f[((1 * 2 + ((q + 1) >> 4)) * 16 + ((q + 1) & 15)) * 64 + lane];
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const int kt = g4 >> 2, r0 = 4 * (g4 & 3);
+                float4 n0 = a0, n1 = a1;
+                if (g4 + 1 < 8) {
+                    n0 = wq[((0 * 2 + ((g4 + 1) >> 2)) * 4 + ((g4 + 1) & 3)) * 64];
+                    n1 = wq[((1 * 2 + ((g4 + 1) >> 2)) * 4 + ((g4 + 1) & 3)) * 64];
                 }
-                H2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, H1[kt][r], H2[0], 0, 0, 0);
-                H2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, H1[kt][r], H2[1], 0, 0, 0);
+                H2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, H1[kt][r0 + 0], H2[0], 0, 0, 0);
+                H2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, H1[kt][r0 + 0], H2[1], 0, 0, 0);
+                H2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, H1[kt][r0 + 1], H2[0], 0, 0, 0);
+                H2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, H1[kt][r0 + 1], H2[1], 0, 0, 0);
+                H2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, H1[kt][r0 + 2], H2[0], 0, 0, 0);
+                H2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, H1[kt][r0 + 2], H2[1], 0, 0, 0);
+                H2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, H1[kt][r0 + 3], H2[0], 0, 0, 0);
+                H2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, H1[kt][r0 + 3], H2[1], 0, 0, 0);
                 a0 = n0; a1 = n1;
             }
         }
@@ -401,17 +417,24 @@ __global__ void __launch_bounds__(512, 2) rs_ppo_grad2_kernel(RsMlpParams prm, r
 #pragma unroll
             for (int r = 0; r < 16; ++r) D1[it][r] = 0.f;
         {
-            float a0 = w2tf[((0 * 2 + 0) * 16 + 0) * 64 + lane], a1 = w2tf[((1 * 2 + 0) * 16 + 0) * 64 + lane];
+            const float4* wq = reinterpret_cast<const float4*>(w2tf) + lane;
+            float4 a0 = wq[0], a1 = wq[(1 * 2 + 0) * 4 * 64];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int kt = q >> 4, r = q & 15;
-                float n0 = 0.f, n1 = 0.f;
-                if (q + 1 < 32) {
-                    n0 = w2tf[((0 * 2 + ((q + 1) >> 4)) * 16 + ((q + 1) & 15)) * 64 + lane];
-                    n1 = w2tf[((1 * 2 + ((q + 1) >> 4)) * 16 + ((q + 1) & 15)) * 64 + lane];
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const int kt = g4 >> 2, r0 = 4 * (g4 & 3);
+                float4 n0 = a0, n1 = a1;
+                if (g4 + 1 < 8) {
+                    n0 = wq[((0 * 2 + ((g4 + 1) >> 2)) * 4 + ((g4 + 1) & 3)) * 64];
+                    n1 = wq[((1 * 2 + ((g4 + 1) >> 2)) * 4 + ((g4 + 1) & 3)) * 64];
                 }
-                D1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, H2[kt][r], D1[0], 0, 0, 0);
-                D1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, H2[kt][r], D1[1], 0, 0, 0);
+                D1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, H2[kt][r0 + 0], D1[0], 0, 0, 0);
+                D1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, H2[kt][r0 + 0], D1[1], 0, 0, 0);
+                D1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, H2[kt][r0 + 1], D1[0], 0, 0, 0);
+                D1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, H2[kt][r0 + 1], D1[1], 0, 0, 0);
+                D1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, H2[kt][r0 + 2], D1[0], 0, 0, 0);
+                D1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, H2[kt][r0 + 2], D1[1], 0, 0, 0);
+                D1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, H2[kt][r0 + 3], D1[0], 0, 0, 0);
+                D1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, H2[kt][r0 + 3], D1[1], 0, 0, 0);
                 a0 = n0; a1 = n1;
             }
         }
