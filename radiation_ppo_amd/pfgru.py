@@ -90,6 +90,30 @@ def pack_weights(cells) -> torch.Tensor:
     return torch.stack(rows).contiguous()
 
 
+class _Linear3D(torch.autograd.Function):
+    """y = x W^T + b for x [B, P, K] with a weight gradient that is reduced in two steps: per-b partial products [B, K, O] (one
+    batched GEMM) and a sum over b.  autograd's own dW = x.reshape(B * P, K)^T @ g.reshape(B * P, O) is a tall-skinny GEMM with a
+    reduction length of B * P ~ 1e5-1e6 and a 27 x 48 output, for which the BLAS library takes ~240 us (30x its memory time): three
+    of those per PFGRU step were 44 % of the GPU time of a RAD-A2C update (profiles/r02_rnn_update_kernel_stats.csv)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(g.transpose(1, 2), x).sum(dim=0) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=(0, 1)) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _lin(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    return _Linear3D.apply(x, layer.weight, layer.bias) if (x.dim() == 3 and torch.is_grad_enabled()) else layer(x)
+
+
 class PFGRUCell(nn.Module):
     """Batched PFGRUCell.  h [B, P, H] particles, p [B, P] log weights (B = envs, or owners x envs)."""
 
@@ -105,6 +129,10 @@ class PFGRUCell(nn.Module):
         self.fc_n = nn.Linear(hidden_size + input_size, hidden_size * 2)
         self.fc_obs = nn.Linear(hidden_size + input_size, 1)
         self.hid_obs = nn.Sequential(nn.Linear(hidden_size, 24), nn.ReLU(), nn.Linear(24, 2), nn.ReLU())    # :1574-1584
+
+    def particle_predictions(self, h: torch.Tensor) -> torch.Tensor:
+        """hid_obs applied to every particle, [B, P, H] -> [B, P, 2] (update_model's particle_pred, ppo.py:1079)."""
+        return torch.relu(_lin(self.hid_obs[2], torch.relu(_lin(self.hid_obs[0], h))))
 
     def init_hidden(self, batch: int, u: Optional[torch.Tensor] = None, device=None):
         """init_hidden (:1643-1652): h0 ~ U[0,1) (`u` [B, P, H] when the draws are supplied), p0 = log(1 / P)."""
@@ -123,13 +151,13 @@ class PFGRUCell(nn.Module):
         B, P, H = h0.shape
         obs_in = obs.unsqueeze(1).expand(B, P, obs.shape[-1])
         obs_cat = torch.cat((h0, obs_in), dim=2)
-        z = torch.sigmoid(self.fc_z(obs_cat))
-        r = torch.sigmoid(self.fc_r(obs_cat))
-        n_1 = self.fc_n(torch.cat((r * h0, obs_in), dim=2))
+        z = torch.sigmoid(_lin(self.fc_z, obs_cat))
+        r = torch.sigmoid(_lin(self.fc_r, obs_cat))
+        n_1 = _lin(self.fc_n, torch.cat((r * h0, obs_in), dim=2))
         mu_n, var_n = torch.split(n_1, H, dim=2)
         n = torch.tanh(mu_n + eps * F.softplus(var_n))
         h1 = (1 - z) * n + z * h0
-        p1 = F.log_softmax(self.fc_obs(torch.cat((h1, obs_in), dim=2)).squeeze(-1) + p0, dim=1)        # :1633-1641
+        p1 = F.log_softmax(_lin(self.fc_obs, torch.cat((h1, obs_in), dim=2)).squeeze(-1) + p0, dim=1)   # :1633-1641
         if self.use_resampling:                                                                          # :1466-1515
             a = self.resamp_alpha
             if resample_idx is None:

@@ -278,7 +278,7 @@ class RNNAgentPPO:
             loc, (h, p) = cell(X3[t], (h, p), draws.eps(t), **draws.resample(t))
             locs.append(loc)
             if want_particles:
-                parts.append(cell.hid_obs(h))                                     # particle_pred[zz] (ppo.py:1079)
+                parts.append(cell.particle_predictions(h))                        # particle_pred[zz] (ppo.py:1079)
         return torch.stack(locs), (torch.stack(parts) if want_particles else None)
 
     def _pfgru_pass_hip(self, X: torch.Tensor, draws: "HashDraws") -> torch.Tensor:
