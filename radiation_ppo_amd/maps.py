@@ -8,11 +8,13 @@ CNNActor/Critic <- Actor :935-1180 / Critic :1183-1345 with the same layer names
                   Flatten(start_dim=1) instead of the reference's batch-1 Flatten(start_dim=0).
 """
 import ctypes as C
+import os
 import math
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from .envs import RadSearchVec
@@ -160,6 +162,39 @@ class ConvTrunk(torch.autograd.Function):
                 g[n1 + 8 + 1152:], None)
 
 
+class _LinearTall(torch.autograd.Function):
+    """y = x W^T + b for a tall x [S, in] (the Linear layers behind the trunk: in = 2704 / 32 / 16): the weight gradient is reduced
+    in two steps (partial products over 1024-row slabs -- 4096 for the wide first layer -- in one batched GEMM, then a sum), because
+    autograd's g^T @ x is a GEMM with a 16 x 32 output and a reduction length of S = 524 288, for which the BLAS library needs
+    0.3-0.9 ms -- 30x its memory time (profiles/r02_final_kernel_stats.csv: the MT32x32x256 / MT16x16x512 kernels).  Config 4's
+    update: 18.0 -> 16.5 s."""
+    SLAB = 1024
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        S = x.shape[0]
+        R = _LinearTall.SLAB if x.shape[1] <= 32 else 4 * _LinearTall.SLAB
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(g.view(S // R, R, -1).transpose(1, 2), x.view(S // R, R, -1)).sum(dim=0)
+        gb = g.sum(dim=0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _head(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if (isinstance(layer, nn.Linear) and x.dim() == 2 and x.shape[0] >= 65536 and x.shape[0] % (4 * _LinearTall.SLAB) == 0
+            and torch.is_grad_enabled()):
+        return _LinearTall.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 class CNNActor(nn.Module):
     """RADTEAM_core.Actor (:935-1180): conv3x3(6->8)-ReLU-maxpool2-conv3x3(8->16)-ReLU-flatten-32-16-8 softmax."""
 
@@ -185,7 +220,7 @@ class CNNActor(nn.Module):
         a = self.actor
         x = ConvTrunk.apply(maps, cells, pcells, agent, a[0].weight, a[0].bias, a[3].weight, a[3].bias, torch.is_grad_enabled())
         for layer in list(a)[6:-1]:
-            x = layer(x)
+            x = _head(layer, x)
         return x
 
     def forward(self, x):
@@ -212,5 +247,5 @@ class CNNCritic(nn.Module):
         c = self.critic
         x = ConvTrunk.apply(maps, None, None, -1, c[0].weight, c[0].bias, c[3].weight, c[3].bias, torch.is_grad_enabled())
         for layer in list(c)[6:]:
-            x = layer(x)
+            x = _head(layer, x)
         return x.squeeze(-1)

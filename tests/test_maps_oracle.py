@@ -42,3 +42,23 @@ def test_maps_match_reference_step_by_step(golden_dir):
         if g["reset_after"][t]:
             for b in bufs:
                 b.reset()
+
+
+def test_tall_linear_two_step_weight_gradient_matches_autograd():
+    """maps._LinearTall (the Linear layers behind the CNN trunk at update-chunk sizes): same outputs and gradients as nn.Linear."""
+    import torch
+    from radiation_ppo_amd.maps import _LinearTall, _head
+    torch.manual_seed(0)
+    for fin, fout in ((32, 16), (16, 8), (48, 32)):
+        lin = torch.nn.Linear(fin, fout).double()
+        x = torch.randn(65536, fin, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(65536, fout, dtype=torch.float64)
+        y_ref = lin(x)
+        gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, lin.weight, lin.bias), g)
+        y = _LinearTall.apply(x, lin.weight, lin.bias)
+        gx, gw, gb = torch.autograd.grad(y, (x, lin.weight, lin.bias), g)
+        assert torch.equal(y, y_ref) and torch.allclose(gx, gx_ref, rtol=1e-12, atol=1e-12)
+        assert torch.allclose(gw, gw_ref, rtol=1e-10, atol=1e-10) and torch.allclose(gb, gb_ref, rtol=1e-10, atol=1e-10)
+        assert _head(lin, x).grad_fn is not None and "LinearTall" in type(_head(lin, x).grad_fn).__name__
+    small = torch.randn(100, 32, dtype=torch.float64, requires_grad=True)
+    assert "LinearTall" not in type(_head(torch.nn.Linear(32, 16).double(), small).grad_fn).__name__      # small batches: plain nn.Linear
