@@ -370,7 +370,11 @@ class RNNAgentPPO:
         h = draws.gru_h0() if hasattr(draws, "gru_h0") else ac.gru_h0(draws.gru_h0_u())
         # the GRU over the whole (padded) episode batch in one sequence call, as grad_step does (:564): states past an episode's
         # end are computed and never used (weight 0)
-        hs, _ = ac.pi.logits_net.v_net.seq_model(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
+        # torch's native GRU path, not MIOpen's: at these sizes MIOpen's RNN backward spends 10 ms per call in one tensor-reduce
+        # kernel (Op2dTensorSquash) and ~1 400 tiny pointwise launches; native: 4.8 s instead of 6.0 s per update at 1024 envs, and
+        # no 4 s first-call warm-up
+        with torch.backends.cudnn.flags(enabled=False):
+            hs, _ = ac.pi.logits_net.v_net.seq_model(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
         logits, val = ac.heads(hs.reshape(L * E, -1))
         logp_all = torch.log_softmax(logits.view(L, E, -1), dim=-1)               # Categorical(logits=...) (:443-446)
         val = val.view(L, E)
