@@ -324,6 +324,22 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
 int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
                    int32_t num_envs, int32_t num_agents, rs_stream_t stream);
 
+/* ---- RAD-A2C GRU recurrence -----------------------------------------------------------------
+ * The time loop of torch.nn.GRU(13, 24, 1) as SeqPt.forward / grad_step run it over whole episodes
+ * (NeuralNetworkCores/RADA2C_core.py:377-381, :550-566) and of its back-propagation through time, for an episode-major batch
+ * (one episode per lane).  Gate order r, z, n; gh = W_hh h + b_hh; n = tanh(gi_n + r * gh_n); h' = (1 - z) n + z h.
+ *   rs_gru_forward : gi [L][E][72] (= X W_ih^T + b_ih, computed by the caller), h0 [E][24],
+ *                    whh_t [24][80] (k-major W_hh^T, columns 72..79 zero), bhh [80] (b_hh, zero padded)
+ *                    -> hs [L][E][24] (h_t), gates [L][E][96] = r | z | n | (W_hn h_{t-1} + b_hn)
+ *   rs_gru_backward: dhs [L][E][24] = dL/dh_t from everything downstream, hs, gates, h0, whh [72][32] (W_hh, columns 24..31 zero)
+ *                    -> dgi [L][E][72] = dL/d(gi), dgh [L][E][72] = dL/d(gh); the caller forms dW_ih = sum dgi^T x,
+ *                       db_ih = sum dgi, dW_hh = sum dgh^T h_{t-1}, db_hh = sum dgh. */
+#define RS_GRU_HIDDEN 24
+int rs_gru_forward(const float* gi, const float* h0, const float* whh_t, const float* bhh, float* hs, float* gates, int32_t steps,
+                   int32_t episodes, rs_stream_t stream);
+int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const float* h0, const float* whh, float* dgi, float* dgh,
+                    int32_t steps, int32_t episodes, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

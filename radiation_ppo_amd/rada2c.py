@@ -105,6 +105,47 @@ class RNNModelActorCritic(nn.Module):
         return (u.float() * 2.0 - 1.0) * std
 
 
+class GRUSequence(torch.autograd.Function):
+    """torch.nn.GRU(13, 24, 1) over an episode-major batch with the recurrence in K12 (csrc/rs_gru.hip): x [L, E, 13], h0 [E, 24]
+    -> h_t [L, E, 24].  Forward: one GEMM for the input projection of all (t, episode), then the time loop in one launch (one
+    episode per lane).  Backward: the time loop in one launch (dL/d gate pre-activations), then the four weight gradients as
+    two-step reductions.  x and h0 receive no gradient (observations / drawn initial states)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+        L, E, K = x.shape
+        H = w_hh.shape[1]
+        assert H == 24 and w_hh.shape[0] == 72 and x.is_cuda
+        lib = _lib.load()
+        x = x.contiguous(); h0 = h0.contiguous()
+        gi = torch.addmm(b_ih, x.view(L * E, K), w_ih.t()).view(L, E, 3 * H)
+        whh_t = torch.zeros(H, 80, dtype=torch.float32, device=x.device); whh_t[:, :3 * H] = w_hh.t()
+        bhh = torch.zeros(80, dtype=torch.float32, device=x.device); bhh[:3 * H] = b_hh
+        hs = torch.empty(L, E, H, dtype=torch.float32, device=x.device)
+        gates = torch.empty(L, E, 4 * H, dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.rs_gru_forward(gi.data_ptr(), h0.data_ptr(), whh_t.data_ptr(), bhh.data_ptr(), hs.data_ptr(), gates.data_ptr(),
+                                      L, E, st), "rs_gru_forward")
+        ctx.save_for_backward(x, h0, w_hh, hs, gates)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x, h0, w_hh, hs, gates = ctx.saved_tensors
+        L, E, H = hs.shape
+        lib = _lib.load()
+        whh = torch.zeros(3 * H, 32, dtype=torch.float32, device=x.device); whh[:, :H] = w_hh
+        dgi = torch.empty(L, E, 3 * H, dtype=torch.float32, device=x.device)
+        dgh = torch.empty_like(dgi)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.rs_gru_backward(dhs.contiguous().data_ptr(), hs.data_ptr(), gates.data_ptr(), h0.data_ptr(), whh.data_ptr(),
+                                       dgi.data_ptr(), dgh.data_ptr(), L, E, st), "rs_gru_backward")
+        h_prev = torch.cat((h0.unsqueeze(0), hs[:-1]), dim=0)
+        gw_ih = torch.bmm(dgi.transpose(1, 2), x).sum(dim=0)               # per-step partial products, then the sum over time
+        gw_hh = torch.bmm(dgh.transpose(1, 2), h_prev).sum(dim=0)
+        return None, None, gw_ih, gw_hh, dgi.sum(dim=(0, 1)), dgh.sum(dim=(0, 1))
+
+
 # ------------------------------------------------------------------------------------------------ draws
 class HashDraws:
     """Counter-hash draws of one pass over an episode batch: keys [E] int64 identify (seed, global env, episode, epoch, pass)."""
@@ -370,11 +411,13 @@ class RNNAgentPPO:
         h = draws.gru_h0() if hasattr(draws, "gru_h0") else ac.gru_h0(draws.gru_h0_u())
         # the GRU over the whole (padded) episode batch in one sequence call, as grad_step does (:564): states past an episode's
         # end are computed and never used (weight 0)
-        # torch's native GRU path, not MIOpen's: at these sizes MIOpen's RNN backward spends 10 ms per call in one tensor-reduce
-        # kernel (Op2dTensorSquash) and ~1 400 tiny pointwise launches; native: 4.8 s instead of 6.0 s per update at 1024 envs, and
-        # no 4 s first-call warm-up
-        with torch.backends.cudnn.flags(enabled=False):
-            hs, _ = ac.pi.logits_net.v_net.seq_model(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
+        g = ac.pi.logits_net.v_net.seq_model
+        if X.is_cuda and ac.hid == 24:
+            # K12: the recurrence and its back-propagation through time in one launch each
+            hs = GRUSequence.apply(torch.cat((X, loc), dim=2), h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
+        else:
+            with torch.backends.cudnn.flags(enabled=False):    # (the library path; on the GPU MIOpen's RNN backward is slower than native)
+                hs, _ = g(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
         logits, val = ac.heads(hs.reshape(L * E, -1))
         logp_all = torch.log_softmax(logits.view(L, E, -1), dim=-1)               # Categorical(logits=...) (:443-446)
         val = val.view(L, E)

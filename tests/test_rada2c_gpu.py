@@ -115,3 +115,25 @@ def test_train_ppo_rnn_end_to_end(tmp_path):
     with pytest.raises(Exception, match="global critic"):
         from radiation_ppo_amd.rada2c import RNNCollector
         RNNCollector(vec, sim.agents, 36, 12, global_critic_flag=True)
+
+
+def test_gru_sequence_kernels_match_torch_gru():
+    """K12 (rs_gru_forward / rs_gru_backward behind rada2c.GRUSequence) against torch.nn.GRU and its autograd: hidden states of
+    every step and all four parameter gradients (float32, different summation order: rtol 1e-4)."""
+    from radiation_ppo_amd.rada2c import GRUSequence
+    torch.manual_seed(2)
+    L, E = 37, 333                                   # not multiples of the wave size
+    gru = torch.nn.GRU(13, 24, 1).cuda()
+    x = torch.randn(L, E, 13, device="cuda")
+    h0 = (torch.rand(E, 24, device="cuda") * 2 - 1) * 0.2
+    wgt = torch.randn(L, E, 24, device="cuda") * (torch.rand(L, E, 1, device="cuda") < 0.7)      # zero on some steps, like padding
+    with torch.backends.cudnn.flags(enabled=False):
+        ref, _ = gru(x, h0.unsqueeze(0))
+    (ref * wgt).sum().backward()
+    want = {k: p.grad.clone() for k, p in gru.named_parameters()}
+    gru.zero_grad()
+    got = GRUSequence.apply(x, h0, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5), float((got - ref).abs().max())
+    (got * wgt).sum().backward()
+    for k, p in gru.named_parameters():
+        assert torch.allclose(p.grad, want[k], rtol=1e-4, atol=1e-3 * float(want[k].abs().max())), (k, float((p.grad - want[k]).abs().max()))
