@@ -1,5 +1,6 @@
 """BASELINE configuration 4 at FULL size -- multi-agent RAD-TEAM, 4 agents, CNN actors + global critic on the heat maps,
-random obstructions, 4096 envs x 480 steps -- through size-independent properties (iterations of the update are reduced,
+random obstructions, 4096 envs x 480 steps; this is also the per-GPU share of configuration 5 (32 768 envs x 4 agents + obstacles on
+8 GPUs: envs shard by env_id_base, which the sharding-invariance property below exercises) -- through size-independent properties (iterations of the update are reduced,
 sizes are not):
   * sharding invariance: every CNNCollector buffer (shared maps, cells, observations, actions, rewards, cuts) of the full
     rollout is bit-identical to two half-size rollouts with env_id_base 0 / 2048; values and log-probabilities, which pass
