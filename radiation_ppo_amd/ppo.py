@@ -182,17 +182,15 @@ class DeviceWelford:
             mean_new = torch.where(m, mean_new, self.mean)
             sq_new = torch.where(m, sq_new, self.sq)
             std_new = torch.where(m, std_new, self.std)
-        self.count, self.mean, self.sq, self.std = count, mean_new, sq_new, std_new
+        # in place: a captured collector step (HIP graph) refers to these tensors by address
+        self.count.copy_(count); self.mean.copy_(mean_new); self.sq.copy_(sq_new); self.std.copy_(std_new)
 
     def standardize(self, reading: torch.Tensor) -> torch.Tensor:
         return ((reading.double() - self.mean) / self.std).float()
 
     def reset(self, mask: torch.Tensor) -> None:
         m = mask.view(-1, *([1] * (self.count.dim() - 1))).expand_as(self.count)
-        self.count = torch.where(m, torch.zeros_like(self.count), self.count)
-        self.mean = torch.where(m, torch.zeros_like(self.mean), self.mean)
-        self.sq = torch.where(m, torch.zeros_like(self.sq), self.sq)
-        self.std = torch.where(m, torch.ones_like(self.std), self.std)
+        self.count.masked_fill_(m, 0.0); self.mean.masked_fill_(m, 0.0); self.sq.masked_fill_(m, 0.0); self.std.masked_fill_(m, 1.0)
 
 
 class RolloutBuffer:

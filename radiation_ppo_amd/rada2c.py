@@ -499,7 +499,7 @@ class RNNCollector:
     """The 'rnn' epoch loop of train_PPO.train for N envs at once (see the module docstring)."""
 
     def __init__(self, env: RadSearchVec, agents: Dict[int, RNNAgentPPO], steps_per_epoch: int, steps_per_episode: int,
-                 global_critic_flag: bool = False):
+                 global_critic_flag: bool = False, use_graph: bool = True):
         if global_critic_flag:
             raise Exception("No global critic option for RAD-A2C")
         self.env, self.agents = env, agents
@@ -519,6 +519,14 @@ class RNNCollector:
             self.bank.cells[a] = ag.agent.model
         self.episodes_begun = torch.zeros(self.N, dtype=torch.int64, device=dev)
         self._gidx = torch.arange(hid, dtype=torch.int64, device=dev)
+        # one lock-step is ~45 small launches: captured once as a HIP graph and replayed (see CNNCollector); all state in place
+        self.use_graph = use_graph
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._t = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._acc = EpochStats(self.A, dev)
+        self._row_act = torch.zeros(self.N, self.A, dtype=torch.int64, device=dev)
+        self._row_f = torch.zeros(3, self.N, self.A, dtype=torch.float32, device=dev)
+        self._src = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
         self.obs = None
         self.started = False
         self.epoch = 0
@@ -532,73 +540,104 @@ class RNNCollector:
         """reset_hidden (:583-586) for the masked envs: fresh particle sets (K11's reset kernel) and GRU h0 ~ U(-1/sqrt(hid), .)."""
         self.bank.reset(mask)
         m = torch.ones(self.N, dtype=torch.bool, device=self.h.device) if mask is None else mask.bool()
-        self.episodes_begun = self.episodes_begun + m.long()
+        self.episodes_begun.add_(m.long())
         key = (self.bank._base * 1000003) ^ ((self.episodes_begun.view(1, -1) * 8 + 5) * _s64(0xA24BAED4963EE407))      # [A, N]
         u = hash_uniform(key.unsqueeze(-1) * 1048583 + self._gidx.view(1, 1, -1))
         h0 = self.agents[0].agent.gru_h0(u)
-        self.h = torch.where(m.view(1, -1, 1), h0, self.h)
+        self.h.copy_(torch.where(m.view(1, -1, 1), h0, self.h))
 
     def start(self) -> None:
         obs, *_ = self.env.reset()
-        self.obs = obs.clone()
+        self.obs = obs.clone()                                    # from here on updated in place (fixed address)
         self.stat.update(self.obs[..., 0])
         self.started = True
 
     @torch.no_grad()
+    def _step(self, epoch_ended: bool) -> None:
+        """One lock-step of train.py:332-548 ('rnn' branches) for all envs; row self._t of the buffers is written."""
+        env, buf, L, N, A = self.env, self.buf, self.L, self.N, self.A
+        acc, ti = self._acc, self._t
+        put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
+        x = self._x(self.obs)                                                 # train.py:334-341
+        env.action_uniforms(self._u)
+        loc = self.bank.predict(x)                                            # PFGRU (K11), carried particle sets
+        for a, ag in self.agents.items():
+            logits, v, h1 = ag.agent.policy_step(x[:, a], loc[:, a], self.h[a])
+            self.h[a] = h1
+            logp_all = torch.log_softmax(logits, dim=-1)
+            cdf = torch.cumsum(logp_all.exp(), dim=-1)
+            act = (cdf[:, :-1] <= self._u[:, a].unsqueeze(-1)).sum(dim=-1)    # inverse CDF on the env's Philox uniform (FF_core.py:101-104)
+            self._row_act[:, a] = act
+            self._row_f[0, :, a] = logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+            self._row_f[1, :, a] = v
+            self._act8[:, a] = act.to(torch.int8)
+        put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
+        put(buf.obs, x)
+        self._src[:, 0] = env.state("src_x")[0].float()
+        self._src[:, 1] = env.state("src_y")[0].float()
+        put(buf.source_tar, self._src)
+        next_obs, rew, team, done, info = env.step(self._act8)
+        put(buf.rew, rew)
+        self.ep_ret += rew
+        self.steps_in_ep += 1
+        terminal = done.bool().any(dim=1)
+        acc.step(info["out_of_bounds"], done)
+        timeout = self.steps_in_ep == L
+        episode_over = terminal | timeout
+        cut = torch.ones_like(episode_over) if epoch_ended else episode_over
+        put(buf.cut, cut.unsqueeze(1).to(torch.uint8).expand(N, A).contiguous())
+        self.stat.update(next_obs[..., 0])
+        self.obs.copy_(next_obs)
+        boot = cut if epoch_ended else timeout                                # train.py:462-487: one more ac.step for the value
+        xb = self._x(self.obs)
+        locb = self.bank.predict(xb, mask=boot)
+        for a, ag in self.agents.items():
+            _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
+            self._row_f[2, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
+        put(buf.last_val, self._row_f[2])
+        acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
+        if epoch_ended:
+            env.set_epoch_end()
+        self.stat.reset(cut)
+        obs_r, *_ = env.reset(cut)
+        self.obs.copy_(obs_r)
+        self.ep_ret.masked_fill_(cut.unsqueeze(1), 0.0)
+        self.steps_in_ep.masked_fill_(cut, 0)
+        self.stat.update(self.obs[..., 0], mask=cut)
+        if not epoch_ended:
+            self._reset_hidden(cut)                                           # train.py:505-518
+        ti.add_(1)
+
+    @torch.no_grad()
     def collect(self) -> Dict[str, torch.Tensor]:
+        """T - 1 replays of one captured lock-step (HIP graph, as in CNNCollector) + the epoch's last step run eagerly."""
         if not self.started:
             self.start()
-        env, buf, T, L, N, A = self.env, self.buf, self.T, self.L, self.N, self.A
-        acc = EpochStats(A, env.device)
-        self._reset_hidden(None)                                                  # train.py:322-329: every epoch starts fresh
-        for t in range(T):
-            x = self._x(self.obs)                                                 # train.py:334-341
-            env.action_uniforms(self._u)
-            loc = self.bank.predict(x)                                            # PFGRU (K11), carried particle sets
-            for a, ag in self.agents.items():
-                logits, v, self.h[a] = ag.agent.policy_step(x[:, a], loc[:, a], self.h[a])
-                logp_all = torch.log_softmax(logits, dim=-1)
-                cdf = torch.cumsum(logp_all.exp(), dim=-1)
-                act = (cdf[:, :-1] <= self._u[:, a].unsqueeze(-1)).sum(dim=-1)    # inverse CDF on the env's Philox uniform (FF_core.py:101-104)
-                buf.act[t, :, a] = act
-                buf.logp[t, :, a] = logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
-                buf.val[t, :, a] = v
-                self._act8[:, a] = act.to(torch.int8)
-            buf.obs[t] = x
-            buf.source_tar[t, :, 0] = env.state("src_x")[0].float()
-            buf.source_tar[t, :, 1] = env.state("src_y")[0].float()
-            next_obs, rew, team, done, info = env.step(self._act8)
-            buf.rew[t] = rew
-            self.ep_ret += rew
-            self.steps_in_ep += 1
-            terminal = done.bool().any(dim=1)
-            acc.step(info["out_of_bounds"], done)
-            timeout = self.steps_in_ep == L
-            episode_over = terminal | timeout
-            epoch_ended = t == T - 1
-            cut = episode_over | epoch_ended
-            buf.cut[t] = cut.unsqueeze(1).to(torch.uint8).expand(N, A)
-            self.stat.update(next_obs[..., 0])
-            self.obs = next_obs.clone()
-            boot = (timeout | epoch_ended) & cut                                  # train.py:462-487: one more ac.step for the value
-            xb = self._x(self.obs)
-            locb = self.bank.predict(xb, mask=boot)
-            for a, ag in self.agents.items():
-                _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
-                buf.last_val[t, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
-            acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
-            if epoch_ended:
-                env.set_epoch_end()
-            self.stat.reset(cut)
-            obs_r, *_ = env.reset(cut)
-            self.obs = obs_r.clone()
-            self.ep_ret = torch.where(cut.unsqueeze(1), torch.zeros_like(self.ep_ret), self.ep_ret)
-            self.steps_in_ep = torch.where(cut, torch.zeros_like(self.steps_in_ep), self.steps_in_ep)
-            self.stat.update(self.obs[..., 0], mask=cut)
-            if not epoch_ended:
-                self._reset_hidden(cut)                                           # train.py:505-518
-        buf.finish(self.agents[0].gamma, self.agents[0].lam)
-        return acc.result()
+        T = self.T
+        self._acc.zero_()
+        self._t.zero_()
+        self._reset_hidden(None)                                              # train.py:322-329: every epoch starts fresh
+        if self.use_graph and self._graph is None and T > 1:
+            side = torch.cuda.Stream(device=self.env.device)                  # library warm-up (GEMM handles) outside the capture
+            side.wait_stream(torch.cuda.current_stream(self.env.device))
+            with torch.cuda.stream(side):
+                x = self._x(self.obs)
+                for a, ag in self.agents.items():
+                    ag.agent.policy_step(x[:, a], torch.zeros(self.N, 2, device=x.device), self.h[a])
+                self.bank._packed()
+            torch.cuda.current_stream(self.env.device).wait_stream(side)
+            torch.cuda.synchronize(self.env.device)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._step(False)
+        for _ in range(T - 1):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step(False)
+        self._step(True)
+        self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
+        return self._acc.result()
 
     def update(self) -> Dict[int, UpdateResult]:
         buf = self.buf

@@ -137,3 +137,27 @@ def test_gru_sequence_kernels_match_torch_gru():
     (got * wgt).sum().backward()
     for k, p in gru.named_parameters():
         assert torch.allclose(p.grad, want[k], rtol=1e-4, atol=1e-3 * float(want[k].abs().max())), (k, float((p.grad - want[k]).abs().max()))
+
+
+def test_rnn_collector_graph_replay_equals_eager_steps():
+    """The captured lock-step replayed T - 1 times writes what the eager loop writes (two epochs; same kernels, same draws)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
+    N, T, L = 48, 26, 8
+
+    def run(use_graph):
+        torch.manual_seed(4)
+        env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=SEED, env_id_base=16)
+        agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, seed=3)}
+        col = RNNCollector(env, agents, T, L, use_graph=use_graph)
+        out = []
+        for _ in range(2):
+            st = col.collect()
+            out.append({**{k: getattr(col.buf, k).clone() for k in ("obs", "act", "rew", "val", "logp", "last_val", "cut", "adv", "ret", "source_tar")},
+                        **{"stat_" + k: v.clone() for k, v in st.items()}})
+        assert (col._graph is not None) == use_graph
+        return out
+    g, e = run(True), run(False)
+    for ep in range(2):
+        for k in e[ep]:
+            assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
