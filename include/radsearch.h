@@ -324,6 +324,12 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
 int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
                    int32_t num_envs, int32_t num_agents, rs_stream_t stream);
 
+/* All draws of one PFGRU training pass over an episode-major batch (the counter hash of rada2c.HashDraws: keys [E] int64):
+ * h0 [E][40][24] initial particles (uniforms), eps [L][E][40][24] reparameterisation noise (standard normals), u [L][E][40]
+ * resampling uniforms (float64).  Replaces torch.rand / FloatTensor.normal_ / torch.multinomial's generator in update_model
+ * (algos/multiagent/ppo.py:1062-1079 via RADA2C_core.py:199-211,279-288) -- the documented RNG deviation. */
+int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* h0, float* eps, double* u, rs_stream_t stream);
+
 /* ---- RAD-A2C GRU recurrence -----------------------------------------------------------------
  * The time loop of torch.nn.GRU(13, 24, 1) as SeqPt.forward / grad_step run it over whole episodes
  * (NeuralNetworkCores/RADA2C_core.py:377-381, :550-566) and of its back-propagation through time, for an episode-major batch

@@ -258,9 +258,53 @@ __global__ void __launch_bounds__(256) rs_pfgru_reset_kernel(float* h, float* p,
     p[i] = -3.6888794541139363f;                                   // float32(log(1 / 40))
 }
 
+// The draws of one training pass over an episode-major batch (rada2c.HashDraws) in one launch instead of ~25 int64 element-wise
+// launches per step: key[e] -> h0 [E][P][H] (uniforms, kind 0), eps [L][E][P][H] (standard normals, kind 1, step t) and
+// u [L][E][P] (resampling uniforms, kind 2, step t).  One lane per (t, episode, particle).
+__global__ void __launch_bounds__(256) rs_pfgru_draws_kernel(const int64_t* __restrict__ key, int E, int L, float* __restrict__ h0,
+                                                             float* __restrict__ eps, double* __restrict__ u) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)L * E * PF_P) return;
+    const int pl = (int)(i % PF_P);
+    const long long te = i / PF_P;
+    const int e = (int)(te % E), t = (int)(te / E);
+    const uint64_t kb = (uint64_t)key[e] * 1000003ull;
+    const uint64_t pu = (uint64_t)pl * 4096ull;
+    const uint64_t k1 = (kb ^ ((uint64_t)(t * 8 + 1) * 0xA24BAED4963EE407ull)) * 1048583ull + pu;
+    float* ew = eps + i * PF_H;
+#pragma unroll
+    for (int q = 0; q < PF_H; q += 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t hx = pf_hash(k1 + (uint64_t)(q + j));
+            const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);
+            const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+            v[j] = sqrtf(-2.0f * logf(u1)) * cosf(6.2831855f * u2);              // pfgru.py: hash_normal (library functions, as torch)
+        }
+        *reinterpret_cast<float4*>(ew + q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const uint64_t k2 = (kb ^ ((uint64_t)(t * 8 + 2) * 0xA24BAED4963EE407ull)) * 1048583ull + pu;
+    u[i] = (double)(pf_hash(k2) >> 11) * (1.0 / 9007199254740992.0);
+    if (t == 0) {
+        const uint64_t k0 = kb * 1048583ull + pu;                                 // kind 0, t 0: (0 * 8 + 0) * C = 0
+        float* hw = h0 + ((long long)e * PF_P + pl) * PF_H;
+#pragma unroll
+        for (int q = 0; q < PF_H; ++q) hw[q] = (float)((double)(pf_hash(k0 + (uint64_t)q) >> 11) * (1.0 / 9007199254740992.0));
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* h0, float* eps, double* u, rs_stream_t stream) {
+    if (!keys || !h0 || !eps || !u || episodes < 1 || steps < 1) return RS_ERR_INVALID_ARG;
+    const long long lanes = (long long)steps * episodes * PF_P;
+    hipLaunchKernelGGL(rs_pfgru_draws_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), keys,
+                       episodes, steps, h0, eps, u);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
                    int32_t num_envs, int32_t num_agents, rs_stream_t stream) {

@@ -172,6 +172,29 @@ class HashDraws:
         return dict(resample_u=hash_uniform(self._key(2, t).view(-1, 1) * 1048583 + self._pu[:, 0].unsqueeze(0)))
 
 
+class KernelDraws:
+    """HashDraws with every draw of the pass produced by ONE launch (rs_pfgru_draws) instead of ~25 int64 element-wise launches per
+    step; same keys, same hash, same values (the normals to float32 rounding of the library log / cos)."""
+
+    def __init__(self, keys: torch.Tensor, L: int):
+        self.k = keys.contiguous()
+        E, dev = keys.shape[0], keys.device
+        self._pf = torch.empty(E, 40, 24, dtype=torch.float32, device=dev)
+        self._eps = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
+        self._u = torch.empty(L, E, 40, dtype=torch.float64, device=dev)
+        _lib.check(_lib.load().rs_pfgru_draws(self.k.data_ptr(), E, L, self._pf.data_ptr(), self._eps.data_ptr(), self._u.data_ptr(),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_draws")
+
+    def pf_h0(self):
+        return self._pf
+
+    def eps(self, t):
+        return self._eps[t]
+
+    def resample(self, t):
+        return dict(resample_u=self._u[t])
+
+
 class RecordedDraws:
     """The reference's own draws (tests): pf_h0 [E, P, H], gru_h0 [E, hid], eps [L, E, P, H], idx [L, E, P]."""
 
@@ -383,7 +406,12 @@ class RNNAgentPPO:
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
             for lo in range(0, E, self.episode_chunk):
                 sl = slice(lo, min(lo + self.episode_chunk, E))
-                d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 1 + it)
+                if draws_for is not None:
+                    d = draws_for(it, sl)
+                elif self.device.type == "cuda":
+                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.X.shape[0])
+                else:
+                    d = HashDraws(B.key[sl] * 64 + 1 + it)
                 loss = self.model_loss(B, sl, d)
                 loss.backward()
                 tot += loss.detach().double()

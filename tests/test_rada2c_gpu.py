@@ -161,3 +161,15 @@ def test_rnn_collector_graph_replay_equals_eager_steps():
     for ep in range(2):
         for k in e[ep]:
             assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
+
+
+def test_kernel_draws_equal_hash_draws():
+    """rs_pfgru_draws (one launch per training pass) against the torch composition of the same counter hash (rada2c.HashDraws)."""
+    from radiation_ppo_amd.rada2c import HashDraws, KernelDraws
+    keys = (torch.arange(257, dtype=torch.int64, device="cuda") * 7919 + 12345) * 64 + 3
+    L = 9
+    kd, hd = KernelDraws(keys, L), HashDraws(keys)
+    assert torch.equal(kd.pf_h0(), hd.pf_h0())
+    for t in range(L):
+        assert torch.equal(kd.resample(t)["resample_u"], hd.resample(t)["resample_u"]), t
+        assert torch.allclose(kd.eps(t), hd.eps(t), rtol=2e-6, atol=2e-6), (t, float((kd.eps(t) - hd.eps(t)).abs().max()))
