@@ -38,25 +38,63 @@ struct rs_maps {
 #define RS_MAPERR_VISIT_OVERFLOW 2u
 
 // ------------------------------------------------------------------------------------------------
-// median of the readings recorded in `cell` (statistics.median: mean of the two middle values when even)
-__device__ __forceinline__ double rs_cell_median(const RsMapsParams& M, int n, int cellidx) {
+// median of the readings recorded in `cell` (statistics.median: mean of the two middle values when even).
+// The chain of the cell is walked ONCE (a pointer chase: one memory latency per entry) into the lane's column of an LDS buffer;
+// the rank counting then runs over that column.  (The first version chased the chain again inside both rank loops: O(m^2)
+// dependent loads -- with a trained policy, whose agents revisit the cells around the source, the collector step of config 4
+// slowed down 2.6x over 30 epochs, scripts/epoch_times_cnn.py.)  The buffer holds min(ring capacity, 512) entries per lane (the ring
+// capacity is steps_per_episode x agents = 480 for the reference's settings: 120 KB of LDS per 64-env block -- the grid has only N / 64
+// blocks, so one block per CU is all it needs); chains longer than the buffer take the chasing path.
+#define RS_MED_CAP_MAX 512
+__device__ __forceinline__ double rs_cell_median(const RsMapsParams& M, int n, int cellidx, float (*buf)[64], int medcap) {
     const float* val = M.ring_val + (size_t)n * M.cap;
     const uint16_t* prv = M.ring_prev + (size_t)n * M.cap;
+    const int lane = threadIdx.x & 63;
+    const int head = M.head[(size_t)n * M.C + cellidx];
     int m = 0;
-    for (int j = M.head[(size_t)n * M.C + cellidx]; j != 0; j = prv[j - 1]) ++m;
-    // k-th smallest by rank counting along the chain (chains are short: an agent rarely stays in a cell)
+    for (int j = head; j != 0; j = prv[j - 1]) {
+        if (m < medcap) buf[m][lane] = val[j - 1];
+        ++m;
+    }
     const int k_lo = (m - 1) / 2, k_hi = m / 2;
     double v_lo = 0.0, v_hi = 0.0;
+    if (m <= medcap) {
+        // Hoare's selection of the k_hi-th smallest inside the lane's LDS column (expected O(m)); afterwards everything left of
+        // k_hi is <= it, so for an even count the other middle value is the maximum of that part.  Only VALUES matter for a
+        // median, so this equals the rank-counting result below bit for bit.
+        int lo = 0, hi = m - 1;
+        while (lo < hi) {
+            const float pivot = buf[(lo + hi) >> 1][lane];
+            int i = lo, j = hi;
+            while (i <= j) {
+                while (buf[i][lane] < pivot) ++i;
+                while (buf[j][lane] > pivot) --j;
+                if (i <= j) {
+                    const float t = buf[i][lane]; buf[i][lane] = buf[j][lane]; buf[j][lane] = t;
+                    ++i; --j;
+                }
+            }
+            if (k_hi <= j) hi = j; else if (k_hi >= i) lo = i; else break;
+        }
+        const float vh = buf[k_hi][lane];
+        float vl = vh;
+        if (k_lo != k_hi) {
+            vl = buf[0][lane];
+            for (int q = 1; q < k_hi; ++q) vl = fmaxf(vl, buf[q][lane]);
+        }
+        return (k_lo == k_hi) ? (double)vh : ((double)vl + (double)vh) / 2.0;
+    }
+    // chains longer than the buffer: k-th smallest by rank counting along the chain; ties broken by chain position
     int ia = 0;
-    for (int a = M.head[(size_t)n * M.C + cellidx]; a != 0; a = prv[a - 1], ++ia) {
+    for (int a = head; a != 0; a = prv[a - 1], ++ia) {
         const float va = val[a - 1];
         int less = 0, eq_before = 0, ib = 0;
-        for (int b = M.head[(size_t)n * M.C + cellidx]; b != 0; b = prv[b - 1], ++ib) {
+        for (int b = head; b != 0; b = prv[b - 1], ++ib) {
             const float vb = val[b - 1];
             less += (vb < va) ? 1 : 0;
             eq_before += (vb == va && ib < ia) ? 1 : 0;
         }
-        const int rank = less + eq_before;          // a strict total order: ties broken by chain position
+        const int rank = less + eq_before;
         if (rank == k_lo) v_lo = (double)va;
         if (rank == k_hi) v_hi = (double)va;
     }
@@ -64,7 +102,9 @@ __device__ __forceinline__ double rs_cell_median(const RsMapsParams& M, int n, i
 }
 
 __global__ void __launch_bounds__(64) rs_maps_update_kernel(RsMapsParams M, RsParams E, const float* __restrict__ obs,
-                                                            const float* __restrict__ pred, const uint8_t* __restrict__ mask) {
+                                                            const float* __restrict__ pred, const uint8_t* __restrict__ mask, int medcap) {
+    extern __shared__ __align__(16) float med_dyn[];
+    float (*med_buf)[64] = reinterpret_cast<float (*)[64]>(med_dyn);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= M.N || (mask && !mask[n])) return;
     const int A = M.A, C = M.C;
@@ -113,7 +153,7 @@ __global__ void __launch_bounds__(64) rs_maps_update_kernel(RsMapsParams M, RsPa
         if (last >= 0) comb[last] -= 1.0f;
         comb[c] += 1.0f;
         // readings: median estimate -> Welford -> z-score (:844-872, StatisticStandardization :215-265)
-        const double est = rs_cell_median(M, n, c);
+        const double est = rs_cell_median(M, n, c, med_buf, medcap);
         wc += 1;
         if (wc == 1) wmean = est;
         else {
@@ -259,8 +299,12 @@ int rs_maps_reset(rs_maps* m, const uint8_t* mask, rs_stream_t stream) {
 int rs_maps_update(rs_maps* m, rs_handle* env, const float* obs, const float* pred, const uint8_t* mask, rs_stream_t stream) {
     if (!m || !env || !obs) return RS_ERR_INVALID_ARG;
     if (env->P.N != m->P.N || env->P.A != m->P.A) return RS_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(rs_maps_update_kernel, dim3((m->P.N + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), m->P, env->P, obs,
-                       pred, mask);
+    const int medcap = m->P.cap < RS_MED_CAP_MAX ? m->P.cap : RS_MED_CAP_MAX;
+    const size_t lds = (size_t)medcap * 64 * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rs_maps_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RS_ERR_HIP;
+    hipLaunchKernelGGL(rs_maps_update_kernel, dim3((m->P.N + 63) / 64), dim3(64), lds, static_cast<hipStream_t>(stream), m->P, env->P, obs,
+                       pred, mask, medcap);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
