@@ -440,7 +440,7 @@ class RNNAgentPPO:
         # the GRU over the whole (padded) episode batch in one sequence call, as grad_step does (:564): states past an episode's
         # end are computed and never used (weight 0)
         g = ac.pi.logits_net.v_net.seq_model
-        if X.is_cuda and ac.hid == 24:
+        if X.is_cuda and ac.hid == 24 and getattr(self, "use_k12", True):
             # K12: the recurrence and its back-propagation through time in one launch each
             hs = GRUSequence.apply(torch.cat((X, loc), dim=2), h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
         else:

@@ -173,3 +173,33 @@ def test_kernel_draws_equal_hash_draws():
     for t in range(L):
         assert torch.equal(kd.resample(t)["resample_u"], hd.resample(t)["resample_u"]), t
         assert torch.allclose(kd.eps(t), hd.eps(t), rtol=2e-6, atol=2e-6), (t, float((kd.eps(t) - hd.eps(t)).abs().max()))
+
+
+def test_policy_update_with_k12_equals_library_gru_path():
+    """One update_rada2c pass with the GRU recurrence on K12 against the same pass on torch.nn.GRU + autograd (same draws, same
+    batch): statistics and every pi gradient."""
+    from radiation_ppo_amd.rada2c import HashDraws, RNNAgentPPO, pack_episodes
+    g = torch.Generator().manual_seed(9)
+    T, N = 60, 96
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    adv, ret = torch.randn(T, N, generator=g).cuda(), torch.randn(T, N, generator=g).cuda()
+    logp = (float(np.log(1 / 8)) + 0.05 * torch.randn(T, N, generator=g)).cuda()
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.08).to(torch.uint8)
+    cut[-1] = 1
+    B = pack_episodes(obs, act, adv, ret, logp, src, cut.cuda(), n_total=N, seed=3)
+    out = []
+    for k12 in (True, False):
+        torch.manual_seed(21)
+        ag = RNNAgentPPO(id=0, seed=1, alpha=0.1)
+        ag.use_k12 = k12
+        ag.agent.train()
+        ag.pi_optimizer.zero_grad(set_to_none=True)
+        loss, st = ag.a2c_losses(B, slice(0, B.lens.shape[0]), HashDraws(B.key * 64 + 17))
+        loss.backward()
+        out.append((st.clone(), {k: p.grad.clone() for k, p in ag.agent.pi.named_parameters()}))
+    assert torch.allclose(out[0][0], out[1][0], rtol=1e-5, atol=1e-7), (out[0][0], out[1][0])
+    for k in out[0][1]:
+        a, b = out[0][1][k], out[1][1][k]
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()) + 1e-9), (k, float((a - b).abs().max()), float(b.abs().max()))
