@@ -1,0 +1,523 @@
+// rs_pfgru_train.hip -- K13: loss and parameter gradients of the PFGRU location predictor over whole episodes, one launch per
+// pass of update_model.
+//
+// Replaces the body of AgentPPO.update_model's iteration (algos/multiagent/ppo.py:1062-1128: the PFGRU unrolled through every
+// episode, the regression + ELBO loss on the mean prediction and on every particle's prediction, loss.backward()) that
+// radiation_ppo_amd/rada2c.py: RNNAgentPPO.model_loss composes from torch ops (~24 000 small launches per pass through autograd).
+// Cell arithmetic: PFGRUCell.forward (NeuralNetworkCores/RADA2C_core.py / algos/test_cnn/RADTEAM_core.py:1586-1631), soft
+// resampling :1466-1515, reparameterize :1517-1530, as in K11 (rs_pfgru.hip).
+//
+// Mapping: one wave per episode, one particle per lane (40 of 64; lane 40 carries the weighted-mean "particle" through hid_obs).
+// The wave first runs the episode forward, storing every step's resampled particle set (the only saved state: 3.9 KB per step),
+// then walks it backwards: each step's gates are recomputed from the stored input state, the loss terms of the step are formed
+// and differentiated in registers, and the gradient flows to the previous step's particles through the resampling gather (an
+// LDS scatter-add) and the gates.  The small matrix products use wave-uniform weights through the scalar unit (as K11 / K12);
+// the weight gradients are sums over particles of outer products: the per-particle factors are staged transposed in LDS and
+// accumulated on the matrix cores (v_mfma_f32_16x16x4_f32, contraction over the particles) in registers for the whole episode,
+// the two thin ones (fc_obs, hid_obs[2]) in per-lane accumulators reduced once at the end.  Output: one gradient slab and one
+// weighted loss per episode; the caller sums them (fixed order).
+//
+// Resampling indices are constants of the backward pass, as in autograd (torch.searchsorted / multinomial have no gradient).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/radsearch.h"
+
+namespace {
+
+constexpr int P = RS_PFGRU_PARTICLES, H = RS_PFGRU_HIDDEN, IN = 3;      // 40, 24, 3
+// packed weights (floats; packer: radiation_ppo_amd/rada2c.py: pack_train_weights)
+constexpr int T_ZR = 0;                    // [28][48] k-major [h | x | 0] -> [z | r]
+constexpr int T_ZRB = T_ZR + 28 * 48;      // [48]
+constexpr int T_N = T_ZRB + 48;            // [28][48] k-major [r*h | x | 0] -> [mu | var]
+constexpr int T_NB = T_N + 28 * 48;        // [48]
+constexpr int T_O = T_NB + 48;             // fc_obs: w [27], b [1], pad to 32
+constexpr int T_H0 = T_O + 32;             // hid_obs[0] k-major [24][32] (columns 24..31 zero)
+constexpr int T_H0B = T_H0 + 24 * 32;      // [32]
+constexpr int T_H2 = T_H0B + 32;           // hid_obs[2]: w [2][24], b [2], pad to 64
+constexpr int T_ZRT = T_H2 + 64;           // [48][32]: row o = W_zr[o][0..23] (gradient wrt h through z | r)
+constexpr int T_NT = T_ZRT + 48 * 32;      // [48][32]: row o = W_n[o][0..23]
+constexpr int T_H0T = T_NT + 48 * 32;      // [24][32]: row o = hid_obs[0].weight[o][0..23]
+constexpr int T_STRIDE = T_H0T + 24 * 32;
+static_assert(T_STRIDE == RS_PFGRU_TRAIN_WEIGHT_FLOATS, "include/radsearch.h: RS_PFGRU_TRAIN_WEIGHT_FLOATS");
+// gradient slab (floats): dW_zr [48][28] (column 27 = bias) | dW_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28]
+constexpr int G_ZR = 0, G_N = G_ZR + 48 * 28, G_H0 = G_N + 48 * 28, G_H2 = G_H0 + 24 * 25, G_O = G_H2 + 50, G_END = G_O + 28;
+static_assert(G_END <= RS_PFGRU_TRAIN_GRAD_FLOATS, "include/radsearch.h: RS_PFGRU_TRAIN_GRAD_FLOATS");
+
+typedef const float __attribute__((address_space(4))) * cmem_t;
+__device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16); see K11 / K12 for the two
+// code-generation remedies (row blocks closed by a scheduling barrier, results pinned)
+template <int K, int OUTP, typename F>
+__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
+#pragma unroll
+    for (int ch = 0; ch < OUTP / 16; ++ch) {
+        float acc[16], wa[16], wb[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wa[o] = W[16 * ch + o]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k + 1 < K) {
+#pragma unroll
+                for (int o = 0; o < 16; ++o) wb[o] = W[(k + 1) * OUTP + 16 * ch + o];
+            }
+            const float c = cval(k);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[o], c, acc[o]);
+            if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) wa[o] = wb[o];
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            asm volatile("" : "+v"(acc[o]));
+            out[16 * ch + o] = acc[o];
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+
+// gates and candidate state of one particle: z, r, n, es = eps * d softplus(var) / d var, h1 = (1 - z) n + z h0, lg = fc_obs([h1, x])
+__device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const float (&x)[IN], const float (&eps)[H], float (&z)[H],
+                                        float (&r)[H], float (&n)[H], float (&es)[H], float (&h1)[H], float& lg) {
+    float g[48];
+#pragma unroll
+    for (int o = 0; o < 48; ++o) g[o] = W[T_ZRB + o];
+    mv<28, 48>(W + T_ZR, [&](int k) -> float { return k < H ? h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, g);
+#pragma unroll
+    for (int u = 0; u < H; ++u) { z[u] = sigmoidf_(g[u]); r[u] = sigmoidf_(g[H + u]); }
+    float m[48];
+#pragma unroll
+    for (int o = 0; o < 48; ++o) m[o] = W[T_NB + o];
+    mv<28, 48>(W + T_N, [&](int k) -> float { return k < H ? r[k < H ? k : 0] * h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, m);
+    lg = W[T_O + 27];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+        const float var = m[H + u];
+        const float e = __builtin_amdgcn_exp2f(1.44269504f * var);
+        const bool big = var > 20.0f;                                                // F.softplus: identity (slope 1) beyond 20
+        const float sp = big ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + e);
+        es[u] = big ? eps[u] : eps[u] * (1.0f - __builtin_amdgcn_rcpf(1.0f + e));
+        const float y = m[u] + eps[u] * sp;
+        n[u] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));      // tanh
+        h1[u] = (1.0f - z[u]) * n[u] + z[u] * h0[u];
+        lg = fmaf(W[T_O + u], h1[u], lg);
+    }
+#pragma unroll
+    for (int k = 0; k < IN; ++k) lg = fmaf(W[T_O + H + k], x[k], lg);
+}
+
+struct TrArgs {
+    const float* w;           // [T_STRIDE]
+    const float* obs;         // [L][E][11] (columns 0..2 feed the PFGRU)
+    const float* tar;         // [L][E][2]  source location / area scale
+    const float* bp;          // [L][E]     normalised exp(bp_decay * t) weights of the episode's steps
+    const int64_t* lens;      // [E]
+    const float* w_ep;        // [E]        weight of the episode's loss
+    const float* h0;          // [E][P][H]  initial particles
+    const float* eps;         // [L][E][P][H]
+    const double* u;          // [L][E][P]  resampling uniforms
+    float* hs;                // [L][E][P][H] scratch: resampled particles after every step
+    float* ps;                // [L][E][P]    scratch: their log weights
+    int32_t* idx;             // [L][E][P]    resampling indices (output; constants of the backward pass)
+    float* loss;              // [E]
+    float* grads;             // [E][RS_PFGRU_TRAIN_GRAD_FLOATS]
+    int L, E;
+    float alpha, floor_, l2w, l1w, elbo;
+};
+
+constexpr int ROW = H + 1;                 // 25: odd stride
+constexpr int TILE_F = 44 * ROW;           // [44][25] particle rows (gather / scatter-add / column sums)
+constexpr int SP = 45;                     // staging row stride: 44 particle columns + 1
+constexpr int DT_F = 48 * SP, IT_F = 32 * SP;
+constexpr int LDS_FLOATS = TILE_F + 2 * P /* cdf (f64) */ + 64 + DT_F + IT_F;
+
+// acc[ti][tj] += D^T I over the particles: DT [16 TI][SP] (row = output unit, column = particle), IT [16 TJ][SP]
+template <int TI, int TJ>
+__device__ __forceinline__ void outer_acc(const float* DT, const float* IT, f4 (&acc)[TI][TJ], int lane) {
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        float a[TI], b[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) a[ti] = DT[(16 * ti + c) * SP + 4 * s + q];
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) b[tj] = IT[(16 * tj + c) * SP + 4 * s + q];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void outer_store(const f4 (&acc)[TI][TJ], float* out, int rows, int cols, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * ti + 4 * q + v, col = 16 * tj + c;
+                if (row < rows && col < cols) out[row * cols + col] = acc[ti][tj][v];
+            }
+}
+
+__global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
+    __shared__ __align__(16) float smem[LDS_FLOATS];
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    float* tile = smem;                                              // [44][ROW]
+    double* cdf = reinterpret_cast<double*>(smem + TILE_F);          // [P]
+    float* vec = smem + TILE_F + 2 * P;                              // [64]
+    float* DT = vec + 64;                                            // [48][SP]
+    float* IT = DT + DT_F;                                           // [32][SP]
+    for (int i = lane; i < DT_F + IT_F; i += 64) DT[i] = 0.0f;       // rows 28..31 of IT stay zero for the whole kernel
+
+    const bool act = lane < P;
+    const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
+    // the weight pointer is laundered once per time step (wptr): the weights are loop invariant, and LICM would otherwise hoist all
+    // 7.5 k scalar loads out of the time loops and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
+    auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
+    const int E = a_.E;
+    const int len = (int)a_.lens[e];
+    const float al = a_.alpha, floor_ = a_.floor_;
+    const size_t PH = (size_t)P * H;
+
+    auto load24 = [&](const float* src, float (&dst)[H]) {
+#pragma unroll
+        for (int u = 0; u < H; u += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + u);
+            dst[u] = v.x; dst[u + 1] = v.y; dst[u + 2] = v.z; dst[u + 3] = v.w;
+        }
+    };
+    auto load_x = [&](int t, float (&x)[IN]) {
+        const cmem_t o = as_cmem(a_.obs + ((size_t)t * E + e) * RS_OBS_DIM);
+#pragma unroll
+        for (int k = 0; k < IN; ++k) x[k] = o[k];
+    };
+
+    // ------------------------------------------------------------------------------------------ forward through the episode
+    {
+        float h0[H];
+        load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
+        float p0 = -3.6888794541139363f;                             // float32(log(1 / 40))
+        for (int t = 0; t < len; ++t) {
+            const cmem_t W = wptr();
+            const size_t te = (size_t)t * E + e;
+            float x[IN], eps[H], z[H], r[H], n[H], es[H], h1[H], lg;
+            load_x(t, x);
+            load24(a_.eps + te * PH + (size_t)pl * H, eps);
+            pf_cell(W, h0, x, eps, z, r, n, es, h1, lg);
+            lg += p0;
+            const float mx = wave_max(act ? lg : -INFINITY);
+            const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
+            const float p1 = (lg - mx) - logf(se);
+            double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {                       // inclusive scan over the lanes (float64), as K11
+                const double tt = __shfl_up(c, s);
+                if (lane >= s) c += tt;
+            }
+            const double tot = __shfl(c, P - 1);
+            if (act) cdf[lane] = c / tot;
+#pragma unroll
+            for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = h1[u];
+            vec[lane] = p1;
+            __builtin_amdgcn_wave_barrier();
+            const double ru = a_.u[te * P + pl];
+            int idx = 0;
+            for (int q = 0; q < P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;   // searchsorted(..., right=True)
+            idx = min(idx, P - 1);
+#pragma unroll
+            for (int u = 0; u < H; ++u) h0[u] = tile[idx * ROW + u];
+            float pn = expf(vec[idx]);
+            pn = logf(pn / (al * pn + floor_));
+            const float mx2 = wave_max(act ? pn : -INFINITY);
+            const float lse = logf(wave_sum(act ? expf(pn - mx2) : 0.0f)) + mx2;
+            p0 = pn - lse;
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+                float* hw = a_.hs + te * PH + (size_t)lane * H;
+#pragma unroll
+                for (int u = 0; u < H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
+                a_.ps[te * P + lane] = p0;
+                a_.idx[te * P + lane] = idx;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ backward through the episode
+    f4 accZR[3][2], accN[3][2], accH0[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { accZR[i][j] = f4{0, 0, 0, 0}; accN[i][j] = f4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accH0[i][j] = f4{0, 0, 0, 0};
+    float aw2[2][ROW], awo[28];
+#pragma unroll
+    for (int k = 0; k < ROW; ++k) { aw2[0][k] = 0.0f; aw2[1][k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 28; ++k) awo[k] = 0.0f;
+    float dh[H], dp = 0.0f;
+#pragma unroll
+    for (int u = 0; u < H; ++u) dh[u] = 0.0f;
+    const float G = a_.w_ep[e];
+    const float inv_nel = 1.0f / (float)(2 * len);
+    const float l2w = a_.l2w, l1w = a_.l1w, elbo = a_.elbo;
+    float l2s = 0.0f, l1s = 0.0f, l2ps = 0.0f, l1ps = 0.0f;          // the episode's four loss terms (wave-uniform)
+    const bool stage = lane < 44;                                    // the lanes that own a staging column
+    const bool act41 = lane <= P;                                    // particles + the mean "particle" in lane 40
+
+    for (int t = len - 1; t >= 0; --t) {
+        const cmem_t W = wptr();
+        const size_t te = (size_t)t * E + e;
+        float h0[H], x[IN], z[H], r[H], n[H], es[H], h1[H], lg, p0;
+        {
+            float eps[H];
+            if (t > 0) {
+                load24(a_.hs + (te - E) * PH + (size_t)pl * H, h0);
+                p0 = a_.ps[(te - E) * P + pl];
+            } else {
+                load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
+                p0 = -3.6888794541139363f;
+            }
+            load_x(t, x);
+            load24(a_.eps + te * PH + (size_t)pl * H, eps);
+            pf_cell(W, h0, x, eps, z, r, n, es, h1, lg);
+        }
+        lg += p0;
+        const float mx = wave_max(act ? lg : -INFINITY);
+        const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
+        const float p1 = (lg - mx) - logf(se);
+        const int idx = a_.idx[te * P + pl];
+        float h1r[H];
+        load24(a_.hs + te * PH + (size_t)pl * H, h1r);
+        const float pi = act ? expf(a_.ps[te * P + pl]) : 0.0f;
+
+        // ---- weighted mean of the resampled particles -> vec[0..23]
+#pragma unroll
+        for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = pi * h1r[u];
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int ul = lane < H ? lane : H - 1;
+            float mean = 0.0f;
+            for (int q = 0; q < P; ++q) mean += tile[q * ROW + ul];
+            __builtin_amdgcn_wave_barrier();
+            vec[lane] = mean;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- hid_obs on every particle (lanes 0..39) and on the mean (lane 40)
+        float v[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) v[k] = act ? h1r[k] : vec[k];
+        float uu[32];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) uu[o] = W[T_H0B + o];
+        mv<H, 32>(W + T_H0, [&](int k) -> float { return v[k]; }, uu);
+        float out[2] = {W[T_H2 + 48], W[T_H2 + 49]};
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            uu[k] = fmaxf(uu[k], 0.0f);
+            out[0] = fmaf(W[T_H2 + k], uu[k], out[0]);
+            out[1] = fmaf(W[T_H2 + H + k], uu[k], out[1]);
+        }
+        out[0] = fmaxf(out[0], 0.0f); out[1] = fmaxf(out[1], 0.0f);
+        // ---- the step's loss terms and d loss / d out
+        const cmem_t tr = as_cmem(a_.tar + te * 2);
+        const float bpt = as_cmem(a_.bp + te)[0];
+        float dop[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float d = out[c] - tr[c];
+            const float e2 = act ? expf(-d * d * bpt) : 0.0f;
+            const float y2 = wave_sum(e2) * (1.0f / P);
+            float gpart = l2w * 2.0f * d * bpt * e2 / (P * y2);
+            l2ps += -logf(y2);
+            if (l1w != 0.0f) {
+                const float e1 = act ? expf(-fabsf(d) * bpt) : 0.0f;
+                const float y1 = wave_sum(e1) * (1.0f / P);
+                const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+                gpart += l1w * 10.0f * sg * bpt * e1 / (P * y1);
+                l1ps += -logf(y1);
+            }
+            const float dm = __shfl(d, P);                           // the mean prediction's error (lane 40)
+            const float sgm = dm > 0.0f ? 1.0f : (dm < 0.0f ? -1.0f : 0.0f);
+            l2s += dm * dm * bpt;
+            l1s += fabsf(dm) * bpt;
+            const float gmean = l2w * 2.0f * d * bpt + l1w * 10.0f * sgm * bpt * inv_nel;
+            const float dout = act ? G * elbo * gpart * inv_nel : (lane == P ? G * gmean : 0.0f);
+            dop[c] = out[c] > 0.0f ? dout : 0.0f;
+        }
+        // ---- hid_obs backwards: thin gradients in per-lane accumulators, hid_obs[0]'s on the matrix cores
+        float du[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            aw2[0][k] = fmaf(dop[0], uu[k], aw2[0][k]);
+            aw2[1][k] = fmaf(dop[1], uu[k], aw2[1][k]);
+            du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
+        }
+        aw2[0][H] += dop[0]; aw2[1][H] += dop[1];
+        float dv[32];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) dv[o] = 0.0f;
+        mv<H, 32>(W + T_H0T, [&](int o) -> float { return du[o]; }, dv);
+        if (stage) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) { DT[k * SP + lane] = act41 ? du[k] : 0.0f; IT[k * SP + lane] = act41 ? v[k] : 0.0f; }
+            IT[H * SP + lane] = act41 ? 1.0f : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        outer_acc<2, 2>(DT, IT, accH0, lane);
+        __builtin_amdgcn_wave_barrier();
+        // ---- gradient at the resampled particles and their log weights
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const float dmean = __shfl(dv[k], P);
+            dh[k] = dh[k] + dv[k] + pi * dmean;                      // dL / d h1r
+            dot = fmaf(dmean, h1r[k], dot);
+        }
+        const float dp1r = dp + pi * dot;
+        const float S = wave_sum(act ? dp1r : 0.0f);
+        const float dpn = dp1r - pi * S;                             // through p1r = pn - logsumexp(pn)
+        vec[lane] = p1;
+        __builtin_amdgcn_wave_barrier();
+        const float wj = expf(vec[idx]);
+        const float gp = dpn * floor_ / (al * wj + floor_);          // through pn = log(w / (alpha w + floor))
+        // ---- back through the gather: scatter-add to the source particles
+#pragma unroll
+        for (int k = 0; k < ROW; ++k) if (act) tile[lane * ROW + k] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < H; ++k) __hip_atomic_fetch_add(&tile[idx * ROW + k], dh[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&tile[idx * ROW + H], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float dh1[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) dh1[k] = tile[pl * ROW + k];
+        const float dp1 = act ? tile[pl * ROW + H] : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        const float dlp = dp1 - expf(p1) * wave_sum(dp1);            // through p1 = lp - logsumexp(lp); also d / d p0
+        dp = dlp;
+        // ---- fc_obs
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            awo[k] = fmaf(dlp, h1[k], awo[k]);
+            dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < IN; ++k) awo[H + k] = fmaf(dlp, x[k], awo[H + k]);
+        awo[27] += dlp;
+        // ---- h1 = (1 - z) n + z h0, n = tanh(mu + eps softplus(var))
+        float dan[48], dz[H];
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const float dn = dh1[u] * (1.0f - z[u]);
+            dz[u] = dh1[u] * (h0[u] - n[u]);
+            dh[u] = dh1[u] * z[u];                                   // dL / d h0 (direct path)
+            const float dm = dn * (1.0f - n[u] * n[u]);
+            dan[u] = dm; dan[H + u] = dm * es[u];
+        }
+        if (stage) {
+#pragma unroll
+            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = act ? dan[o] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? r[k] * h0[k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = act ? x[k] : 0.0f;
+            IT[27 * SP + lane] = act ? 1.0f : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        outer_acc<3, 2>(DT, IT, accN, lane);
+        __builtin_amdgcn_wave_barrier();
+        float drh[32];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) drh[o] = 0.0f;
+        mv<48, 32>(W + T_NT, [&](int o) -> float { return dan[o]; }, drh);
+        // ---- z, r = sigmoid(W_zr [h0, x] + b)
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            dh[u] = fmaf(drh[u], r[u], dh[u]);
+            const float dr = drh[u] * h0[u];
+            dan[u] = dz[u] * z[u] * (1.0f - z[u]);                    // dan now holds d (a_z | a_r)
+            dan[H + u] = dr * r[u] * (1.0f - r[u]);
+        }
+        if (stage) {
+#pragma unroll
+            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = act ? dan[o] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? h0[k] : 0.0f;      // rows 24..27 still hold x | 1
+        }
+        __builtin_amdgcn_wave_barrier();
+        outer_acc<3, 2>(DT, IT, accZR, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int o = 0; o < 32; ++o) drh[o] = 0.0f;
+        mv<48, 32>(W + T_ZRT, [&](int o) -> float { return dan[o]; }, drh);
+#pragma unroll
+        for (int u = 0; u < H; ++u) dh[u] += drh[u];                  // dL / d (h1r of step t - 1), particle by particle
+    }
+
+    // ------------------------------------------------------------------------------------------ the episode's slab
+    float* g = a_.grads + (size_t)e * RS_PFGRU_TRAIN_GRAD_FLOATS;
+    outer_store<3, 2>(accZR, g + G_ZR, 48, 28, lane);
+    outer_store<3, 2>(accN, g + G_N, 48, 28, lane);
+    outer_store<2, 2>(accH0, g + G_H0, 24, 25, lane);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < ROW; ++k) {
+            const float s = wave_sum(act41 ? aw2[c][k] : 0.0f);
+            if (lane == 0) g[G_H2 + c * ROW + k] = s;
+        }
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        const float s = wave_sum(act ? awo[k] : 0.0f);
+        if (lane == 0) g[G_O + k] = s;
+    }
+    if (lane == 0) {
+        const float pred = l2w * l2s + l1w * 10.0f * l1s * inv_nel;
+        const float part = (l2w * l2ps + l1w * 10.0f * l1ps) * inv_nel;
+        a_.loss[e] = G * (pred + elbo * part);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_pfgru_train(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
+                   const float* h0, const float* eps, const double* u, float* hs, float* ps, int32_t* idx, float* loss, float* grads,
+                   int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
+                   rs_stream_t stream) {
+    if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !u || !hs || !ps || !idx || !loss || !grads || steps < 1 ||
+        episodes < 1)
+        return RS_ERR_INVALID_ARG;
+    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, idx, loss, grads, steps, episodes, (float)alpha,
+             (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
+    hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+}  // extern "C"

@@ -270,6 +270,51 @@ def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base:
                         lens=lens, w_ep=w_ep, key=key)
 
 
+# ------------------------------------------------------------------------------------------------ K13 plumbing
+PF_TRAIN_WEIGHT_FLOATS, PF_TRAIN_GRAD_FLOATS = 7520, 3376            # include/radsearch.h
+
+
+def pack_train_weights(cell) -> torch.Tensor:
+    """The PFGRU's parameters in the layout rs_pfgru_train reads (csrc/rs_pfgru_train.hip): k-major forward blocks and the
+    transposed copies the backward products use."""
+    assert cell.h_dim == 24 and cell.num_particles == 40 and cell.input_size == 3, "rs_pfgru_train is built for 40 particles x 24 units"
+    dev = cell.fc_z.weight.device
+    w = torch.zeros(PF_TRAIN_WEIGHT_FLOATS, dtype=torch.float32, device=dev)
+    o = 0
+
+    def put(t, n):
+        nonlocal o
+        w[o:o + t.numel()] = t.reshape(-1)
+        o += n
+    zr = torch.cat([cell.fc_z.weight, cell.fc_r.weight], 0)                       # [48, 27]
+    put(F.pad(zr.t(), (0, 0, 0, 1)), 28 * 48)                                     # [28][48] k-major, row 27 zero
+    put(torch.cat([cell.fc_z.bias, cell.fc_r.bias], 0), 48)
+    put(F.pad(cell.fc_n.weight.t(), (0, 0, 0, 1)), 28 * 48)
+    put(cell.fc_n.bias, 48)
+    put(torch.cat([cell.fc_obs.weight.reshape(-1), cell.fc_obs.bias.reshape(-1)]), 32)
+    put(F.pad(cell.hid_obs[0].weight.t(), (0, 8)), 24 * 32)                       # [24 k][32]
+    put(F.pad(cell.hid_obs[0].bias, (0, 8)), 32)
+    put(torch.cat([cell.hid_obs[2].weight.reshape(-1), cell.hid_obs[2].bias.reshape(-1)]), 64)
+    put(F.pad(zr[:, :24], (0, 8)), 48 * 32)                                       # [48 o][32]
+    put(F.pad(cell.fc_n.weight[:, :24], (0, 8)), 48 * 32)
+    put(F.pad(cell.hid_obs[0].weight, (0, 8)), 24 * 32)                           # [24 o][32]
+    assert o == PF_TRAIN_WEIGHT_FLOATS
+    return w
+
+
+def unpack_train_grads(cell, g: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """A summed gradient slab [PF_TRAIN_GRAD_FLOATS] -> gradients by parameter name (PFGRUCell.named_parameters)."""
+    zr = g[:48 * 28].view(48, 28)
+    n = g[48 * 28:2 * 48 * 28].view(48, 28)
+    o = 2 * 48 * 28
+    h0 = g[o:o + 600].view(24, 25); o += 600
+    h2 = g[o:o + 50].view(2, 25); o += 50
+    fo = g[o:o + 28]
+    return {"fc_z.weight": zr[:24, :27], "fc_z.bias": zr[:24, 27], "fc_r.weight": zr[24:, :27], "fc_r.bias": zr[24:, 27],
+            "fc_n.weight": n[:, :27], "fc_n.bias": n[:, 27], "fc_obs.weight": fo[:27].view(1, 27), "fc_obs.bias": fo[27:28],
+            "hid_obs.0.weight": h0[:, :24], "hid_obs.0.bias": h0[:, 24], "hid_obs.2.weight": h2[:, :24], "hid_obs.2.bias": h2[:, 24]}
+
+
 # ------------------------------------------------------------------------------------------------ agent
 @dataclass
 class BpArgs:
@@ -395,6 +440,31 @@ class RNNAgentPPO:
         total = pred_loss + a.elbo_weight * (a.l2_weight * l2p + a.l1_weight * l1p)
         return (B.w_ep[sl] * total).sum()
 
+    def model_pass_hip(self, B: EpisodeBatch, sl: slice, d: "KernelDraws"):
+        """model_loss + backward for an episode chunk on K13 (rs_pfgru_train): returns (loss, summed gradient slab, idx [L, E, 40])."""
+        a = self.bp_args
+        dev = self.device
+        X = B.X[:, sl].contiguous()
+        L, E = X.shape[0], X.shape[1]
+        valid, lens = B.valid[:, sl], B.lens[sl].contiguous()
+        tar = (B.src[:, sl] / a.area_scale).float().contiguous()
+        tt = torch.arange(L, device=dev, dtype=torch.float64).unsqueeze(1)
+        bp = torch.exp(a.bp_decay * tt) * valid.double()
+        bp = (bp / bp.sum(dim=0, keepdim=True)).float().contiguous()               # :1074-1075
+        w_ep = B.w_ep[sl].float().contiguous()
+        hs = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
+        ps = torch.empty(L, E, 40, dtype=torch.float32, device=dev)
+        idx = torch.empty(L, E, 40, dtype=torch.int32, device=dev)
+        loss = torch.empty(E, dtype=torch.float32, device=dev)
+        slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
+        w = pack_train_weights(self.agent.model)
+        _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
+                                              d._pf.data_ptr(), d._eps.data_ptr(), d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
+                                              idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
+                                              float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
+        return loss.double().sum(), slab.sum(dim=0), idx
+
     def update_model(self, B: EpisodeBatch, draws_for=None) -> float:
         """update_model (ppo.py:1047-1148).  draws_for(iteration, slice) -> draws; default: counter hashes."""
         cell = self.agent.model
@@ -412,6 +482,14 @@ class RNNAgentPPO:
                     d = KernelDraws(B.key[sl] * 64 + 1 + it, B.X.shape[0])
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it)
+                if isinstance(d, KernelDraws) and getattr(self, "use_k13", True):
+                    # K13: the episode loop, the loss and its back-propagation through time in one launch
+                    loss, g, _ = self.model_pass_hip(B, sl, d)
+                    by_name = unpack_train_grads(cell, g)
+                    for name, p in cell.named_parameters():
+                        p.grad = by_name[name].clone() if p.grad is None else p.grad.add_(by_name[name])
+                    tot += loss
+                    continue
                 loss = self.model_loss(B, sl, d)
                 loss.backward()
                 tot += loss.detach().double()

@@ -203,3 +203,110 @@ def test_policy_update_with_k12_equals_library_gru_path():
     for k in out[0][1]:
         a, b = out[0][1][k], out[1][1][k]
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()) + 1e-9), (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+class _KernelIdxDraws:
+    """The draws of a KernelDraws object with the resampling INDICES the kernel took (the discrete choices are then the same on
+    both sides; the uniforms behind them are checked by the forward comparison of the indices themselves)."""
+
+    def __init__(self, kd, idx):
+        self.kd, self.idx = kd, idx
+
+    def pf_h0(self):
+        return self.kd.pf_h0()
+
+    def eps(self, t):
+        return self.kd.eps(t)
+
+    def resample(self, t):
+        return dict(resample_idx=self.idx[t].long())
+
+
+@pytest.mark.parametrize("l1", [0.0, 0.5])
+def test_pfgru_training_kernel_matches_autograd(l1):
+    """K13 (rs_pfgru_train: episode loop + loss + back-propagation through time in one launch) against model_loss + autograd on the
+    torch cell: loss, every parameter gradient, and the resampling indices against the inverse-CDF of the uniforms."""
+    from radiation_ppo_amd.rada2c import BpArgs, KernelDraws, RNNAgentPPO, pack_episodes, unpack_train_grads
+    g = torch.Generator().manual_seed(4)
+    T, N = 40, 24
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    z = torch.zeros(T, N).cuda()
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.08).to(torch.uint8)
+    cut[-1] = 1
+    cut[0, 3] = 1                                                       # a one-step episode
+    B = pack_episodes(obs, act, z, z, z, src, cut.cuda(), n_total=N, seed=3)
+    E = B.lens.shape[0]
+    torch.manual_seed(5)
+    ag = RNNAgentPPO(id=0, seed=1, bp_args=BpArgs(l1_weight=l1, area_scale=2500.0))
+    cell = ag.agent.model
+    with torch.no_grad():                                                # away from the initialisation: every path carries signal
+        for p in cell.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g).cuda())
+    sl = slice(0, E)
+    kd = KernelDraws(B.key * 64 + 1, B.X.shape[0])
+    loss_k, slab, idx = ag.model_pass_hip(B, sl, kd)
+    gk = unpack_train_grads(cell, slab)
+    cell.train()
+    for p in cell.parameters():
+        p.grad = None
+    loss_t = ag.model_loss(B, sl, _KernelIdxDraws(kd, idx))
+    loss_t.backward()
+    lk, lt = float(loss_k), float(loss_t.detach())
+    assert abs(lk - lt) <= 2e-5 * abs(lt), (lk, lt)
+    for name, p in cell.named_parameters():
+        a, b = gk[name], p.grad
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()) + 1e-10), (name, float((a - b).abs().max()), float(b.abs().max()))
+    # the indices themselves: the torch cell resampling from the same uniforms takes the same particles (valid steps)
+    cell.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        h, p = kd.pf_h0(), torch.full((E, 40), float(np.log(1 / 40)), dtype=torch.float32, device="cuda")
+        same = tot = 0
+        for t in range(B.X.shape[0]):
+            X3 = B.X[t, :, :3]
+            pre_h, pre_p = h, p
+            _, (h, p) = cell(X3, (pre_h, pre_p), kd.eps(t), **kd.resample(t))
+            ref_h = torch.gather(_pre_resample(cell, X3, pre_h, pre_p, kd.eps(t)), 1, idx[t].long().unsqueeze(-1).expand(E, 40, 24))
+            ok = ((ref_h - h).abs().amax(dim=(1, 2)) < 1e-6) & B.valid[t]
+            same += int(ok.sum()); tot += int(B.valid[t].sum())
+            # continue from the kernel's choice so that one flipped index (a uniform within rounding of a CDF step) cannot cascade
+            _, (h, p) = cell(X3, (pre_h, pre_p), kd.eps(t), resample_idx=idx[t].long())
+        assert same >= tot - 2, (same, tot)
+
+
+def _pre_resample(cell, X3, h0, p0, eps):
+    keep = cell.use_resampling
+    cell.use_resampling = False
+    try:
+        _, (h1, _) = cell(X3, (h0, p0), eps)
+    finally:
+        cell.use_resampling = keep
+    return h1
+
+
+def test_update_model_on_k13_equals_autograd_path():
+    """update_model end to end (draws, K13 passes, clip, Adam) against the same call on the torch-autograd path: the PFGRU's
+    parameters after two iterations."""
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, pack_episodes
+    g = torch.Generator().manual_seed(8)
+    T, N = 30, 40
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    z = torch.zeros(T, N).cuda()
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.1).to(torch.uint8)
+    cut[-1] = 1
+    B = pack_episodes(obs, act, z, z, z, src, cut.cuda(), n_total=N, seed=3)
+    res = []
+    for k13 in (True, False):
+        torch.manual_seed(6)
+        ag = RNNAgentPPO(id=0, seed=1, train_pfgru_iters=2, episode_chunk=64)        # several chunks
+        ag.use_k13 = k13
+        loss = ag.update_model(B)
+        res.append((loss, {k: v.detach().clone() for k, v in ag.agent.model.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-3 * abs(res[1][0]), (res[0][0], res[1][0])
+    lr = 5e-3
+    for k in res[0][1]:
+        d = float((res[0][1][k] - res[1][1][k]).abs().max())
+        assert d <= 0.25 * lr, (k, d)                                    # an Adam step moves every element by ~lr: same direction everywhere
