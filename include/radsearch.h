@@ -336,14 +336,14 @@ int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* 
  *             + elbo * (l2w * sum_{t,c} -log mean_p exp(-(part_tpc - tar_tc)^2 bp_t) + l1w * 10 * sum_{t,c} -log mean_p exp(-|.| bp_t)) / n_e
  * (n_e = 2 x the episode's length; loc = hid_obs(weighted particle mean), part = hid_obs of every resampled particle), and
  * d (w_ep[e] * total_e) / d parameters by back-propagation through time, resampling indices held constant as in autograd.
- *   weights [RS_PFGRU_TRAIN_WEIGHT_FLOATS]  packed parameters incl. transposed copies (layout: csrc/rs_pfgru_train.hip; packer: rada2c.py)
+ *   weights [RS_PFGRU_TRAIN_WEIGHT_FLOATS]  packed parameters (layout: csrc/rs_pfgru_train.hip; packer: rada2c.py)
  *   obs [L][E][11] (columns 0..2 used), target [L][E][2], bp [L][E], lens [E] (1..L; steps beyond are never touched), w_ep [E]
  *   h0 / eps / u  the draws of rs_pfgru_draws
  *   hs [L][E][40][24], ps [L][E][40]  scratch (the resampled particle sets), idx [L][E][40] the resampling indices taken
  *   loss [E] = w_ep[e] * total_e;  grads [E][RS_PFGRU_TRAIN_GRAD_FLOATS] = the episode's gradient slab:
  *   d[fc_z | fc_r] [48][28] (column 27 = bias) | d fc_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28];
  *   the caller sums the slabs over the episodes. */
-#define RS_PFGRU_TRAIN_WEIGHT_FLOATS 7520
+#define RS_PFGRU_TRAIN_WEIGHT_FLOATS 3680
 #define RS_PFGRU_TRAIN_GRAD_FLOATS 3376
 int rs_pfgru_train(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
                    const float* h0, const float* eps, const double* u, float* hs, float* ps, int32_t* idx, float* loss, float* grads,

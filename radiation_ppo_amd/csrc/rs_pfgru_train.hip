@@ -35,10 +35,8 @@ constexpr int T_O = T_NB + 48;             // fc_obs: w [27], b [1], pad to 32
 constexpr int T_H0 = T_O + 32;             // hid_obs[0] k-major [24][32] (columns 24..31 zero)
 constexpr int T_H0B = T_H0 + 24 * 32;      // [32]
 constexpr int T_H2 = T_H0B + 32;           // hid_obs[2]: w [2][24], b [2], pad to 64
-constexpr int T_ZRT = T_H2 + 64;           // [48][32]: row o = W_zr[o][0..23] (gradient wrt h through z | r)
-constexpr int T_NT = T_ZRT + 48 * 32;      // [48][32]: row o = W_n[o][0..23]
-constexpr int T_H0T = T_NT + 48 * 32;      // [24][32]: row o = hid_obs[0].weight[o][0..23]
-constexpr int T_STRIDE = T_H0T + 24 * 32;
+constexpr int T_STRIDE = T_H2 + 64;        // 14.7 KB: the whole set stays resident in the 16 KB scalar data cache.  A first version kept
+                                           // transposed copies for the backward products (30 KB): every s_load then missed and a step took 3.5x longer
 static_assert(T_STRIDE == RS_PFGRU_TRAIN_WEIGHT_FLOATS, "include/radsearch.h: RS_PFGRU_TRAIN_WEIGHT_FLOATS");
 // gradient slab (floats): dW_zr [48][28] (column 27 = bias) | dW_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28]
 constexpr int G_ZR = 0, G_N = G_ZR + 48 * 28, G_H0 = G_N + 48 * 28, G_H2 = G_H0 + 24 * 25, G_O = G_H2 + 50, G_END = G_O + 28;
@@ -86,6 +84,37 @@ __device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
             asm volatile("" : "+v"(acc[o]));
             out[16 * ch + o] = acc[o];
         }
+    }
+}
+
+// out[k] += sum_o W[k][o] c(o) on the SAME k-major [K][OUTP] block (the transposed product of the backward pass: a dot product
+// along each row).  One 16-weight block per s_load_dwordx16, two blocks requested ahead, two partial sums per row.
+template <int K, int OUTP, typename F>
+__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
+    constexpr int CH = OUTP / 16, NB = K * CH;
+    float wq[3][16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) { wq[0][o] = W[o]; wq[1][o] = W[16 + o]; }
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 2 < NB) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) wq[(b + 2) % 3][o] = W[(b + 2) * 16 + o];
+        }
+        const int k = b / CH, ch = b % CH;
+        if (ch == 0) { a0 = 0.0f; a1 = 0.0f; }
+#pragma unroll
+        for (int o = 0; o < 16; o += 2) {
+            a0 = fmaf(wq[b % 3][o], cval(16 * ch + o), a0);
+            a1 = fmaf(wq[b % 3][o + 1], cval(16 * ch + o + 1), a1);
+        }
+        if (ch == CH - 1) {
+            float r = a0 + a1;
+            asm volatile("" : "+v"(r));
+            out[k] += r;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -191,8 +220,9 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
 
     const bool act = lane < P;
     const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
-    // the weight pointer is laundered once per time step (wptr): the weights are loop invariant, and LICM would otherwise hoist all
-    // 7.5 k scalar loads out of the time loops and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
+    // the weight pointer is laundered once per time step and again before every transposed product (wptr): the weights are loop
+    // invariant and the forward and transposed products read the same rows -- LICM / GVN would otherwise hoist or keep thousands of
+    // scalar loads and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
     auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
     const int E = a_.E;
     const int len = (int)a_.lens[e];
@@ -376,10 +406,10 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
         }
         aw2[0][H] += dop[0]; aw2[1][H] += dop[1];
-        float dv[32];
+        float dv[H];
 #pragma unroll
-        for (int o = 0; o < 32; ++o) dv[o] = 0.0f;
-        mv<H, 32>(W + T_H0T, [&](int o) -> float { return du[o]; }, dv);
+        for (int o = 0; o < H; ++o) dv[o] = 0.0f;
+        mvt<H, 32>(wptr() + T_H0, [&](int o) -> float { return o < H ? du[o < H ? o : 0] : 0.0f; }, dv);
         if (stage) {
 #pragma unroll
             for (int k = 0; k < H; ++k) { DT[k * SP + lane] = act41 ? du[k] : 0.0f; IT[k * SP + lane] = act41 ? v[k] : 0.0f; }
@@ -451,10 +481,10 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<3, 2>(DT, IT, accN, lane);
         __builtin_amdgcn_wave_barrier();
-        float drh[32];
+        float drh[H];
 #pragma unroll
-        for (int o = 0; o < 32; ++o) drh[o] = 0.0f;
-        mv<48, 32>(W + T_NT, [&](int o) -> float { return dan[o]; }, drh);
+        for (int o = 0; o < H; ++o) drh[o] = 0.0f;
+        mvt<H, 48>(wptr() + T_N, [&](int o) -> float { return dan[o]; }, drh);
         // ---- z, r = sigmoid(W_zr [h0, x] + b)
 #pragma unroll
         for (int u = 0; u < H; ++u) {
@@ -472,11 +502,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<3, 2>(DT, IT, accZR, lane);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int o = 0; o < 32; ++o) drh[o] = 0.0f;
-        mv<48, 32>(W + T_ZRT, [&](int o) -> float { return dan[o]; }, drh);
-#pragma unroll
-        for (int u = 0; u < H; ++u) dh[u] += drh[u];                  // dL / d (h1r of step t - 1), particle by particle
+        mvt<H, 48>(wptr() + T_ZR, [&](int o) -> float { return dan[o]; }, dh);                  // dL / d (h1r of step t - 1), particle by particle
     }
 
     // ------------------------------------------------------------------------------------------ the episode's slab

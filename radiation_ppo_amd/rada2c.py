@@ -271,12 +271,12 @@ def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base:
 
 
 # ------------------------------------------------------------------------------------------------ K13 plumbing
-PF_TRAIN_WEIGHT_FLOATS, PF_TRAIN_GRAD_FLOATS = 7520, 3376            # include/radsearch.h
+PF_TRAIN_WEIGHT_FLOATS, PF_TRAIN_GRAD_FLOATS = 3680, 3376            # include/radsearch.h
 
 
 def pack_train_weights(cell) -> torch.Tensor:
-    """The PFGRU's parameters in the layout rs_pfgru_train reads (csrc/rs_pfgru_train.hip): k-major forward blocks and the
-    transposed copies the backward products use."""
+    """The PFGRU's parameters in the layout rs_pfgru_train reads (csrc/rs_pfgru_train.hip): k-major blocks, used by the forward products column-wise
+    and by the backward (transposed) products row-wise."""
     assert cell.h_dim == 24 and cell.num_particles == 40 and cell.input_size == 3, "rs_pfgru_train is built for 40 particles x 24 units"
     dev = cell.fc_z.weight.device
     w = torch.zeros(PF_TRAIN_WEIGHT_FLOATS, dtype=torch.float32, device=dev)
@@ -295,9 +295,6 @@ def pack_train_weights(cell) -> torch.Tensor:
     put(F.pad(cell.hid_obs[0].weight.t(), (0, 8)), 24 * 32)                       # [24 k][32]
     put(F.pad(cell.hid_obs[0].bias, (0, 8)), 32)
     put(torch.cat([cell.hid_obs[2].weight.reshape(-1), cell.hid_obs[2].bias.reshape(-1)]), 64)
-    put(F.pad(zr[:, :24], (0, 8)), 48 * 32)                                       # [48 o][32]
-    put(F.pad(cell.fc_n.weight[:, :24], (0, 8)), 48 * 32)
-    put(F.pad(cell.hid_obs[0].weight, (0, 8)), 24 * 32)                           # [24 o][32]
     assert o == PF_TRAIN_WEIGHT_FLOATS
     return w
 
@@ -454,7 +451,7 @@ class RNNAgentPPO:
         w_ep = B.w_ep[sl].float().contiguous()
         hs = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
         ps = torch.empty(L, E, 40, dtype=torch.float32, device=dev)
-        idx = torch.empty(L, E, 40, dtype=torch.int32, device=dev)
+        idx = torch.zeros(L, E, 40, dtype=torch.int32, device=dev)              # steps beyond an episode's end are never written
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
         w = pack_train_weights(self.agent.model)
