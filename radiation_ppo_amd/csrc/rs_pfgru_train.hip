@@ -57,27 +57,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16); see K11 / K12 for the two
-// code-generation remedies (row blocks closed by a scheduling barrier, results pinned)
+// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16), rows requested two ahead.
+// See K11 / K12 for the code-generation remedies (row blocks closed by a scheduling barrier, results pinned); here the accumulators
+// are pinned at EVERY row as well: pinned only at the end, a whole chunk's FMA chains were still sunk below the barriers in the
+// backward loop, one s_load_dwordx16 + s_waitcnt per FMA (seen in the ISA; 40 -> 30 ms per pass)
 template <int K, int OUTP, typename F>
 __device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
 #pragma unroll
     for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wa[16], wb[16];
+        float acc[16], wq[3][16];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wa[o] = W[16 * ch + o]; }
+        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wq[0][o] = W[16 * ch + o]; wq[1][o] = W[OUTP + 16 * ch + o]; }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k + 1 < K) {
+            if (k + 2 < K) {
 #pragma unroll
-                for (int o = 0; o < 16; ++o) wb[o] = W[(k + 1) * OUTP + 16 * ch + o];
+                for (int o = 0; o < 16; ++o) wq[(k + 2) % 3][o] = W[(k + 2) * OUTP + 16 * ch + o];
             }
             const float c = cval(k);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[o], c, acc[o]);
-            if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % 3][o], c, acc[o]);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) wa[o] = wb[o];
+            for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
@@ -109,11 +111,8 @@ __device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
             a0 = fmaf(wq[b % 3][o], cval(16 * ch + o), a0);
             a1 = fmaf(wq[b % 3][o + 1], cval(16 * ch + o + 1), a1);
         }
-        if (ch == CH - 1) {
-            float r = a0 + a1;
-            asm volatile("" : "+v"(r));
-            out[k] += r;
-        }
+        asm volatile("" : "+v"(a0), "+v"(a1));
+        if (ch == CH - 1) out[k] += a0 + a1;
         __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -27,6 +27,7 @@ Deviations, all forced by batching and stated here: (i) update_model clips the g
 reference clips per rank, then averages, ppo.py:1137-1141); (ii) LocLoss is the RMS over all samples (the reference reports the
 loop's last episode, :1274); (iii) several agents are independent copies, each fed its own observation row.
 """
+import bisect
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -229,15 +230,29 @@ class EpisodeBatch:
     lens: torch.Tensor       # [E] int64
     w_ep: torch.Tensor       # [E] 1 / (global env count x episodes of the env): the weight of an episode's loss
     key: torch.Tensor        # [E] int64 draw keys
+    lens_host: Optional[List[int]] = None
 
     @property
     def w(self) -> torch.Tensor:
         """per-sample weights: w_ep / len on valid steps."""
         return (self.w_ep / self.lens.float()).unsqueeze(0) * self.valid.float()
 
+    def chunk(self, sl: slice) -> "EpisodeBatch":
+        """The episodes sl, trimmed to the longest of them (with episodes sorted by length -- pack_episodes(sort_by_length=True) --
+        later chunks are much shorter than the batch: a learned policy ends most episodes after ~30 of 120 steps)."""
+        if self.lens_host is None:
+            self.lens_host = self.lens.tolist()
+        Lc = max(self.lens_host[sl])
+        return EpisodeBatch(X=self.X[:Lc, sl], act=self.act[:Lc, sl], adv=self.adv[:Lc, sl], ret=self.ret[:Lc, sl], logp=self.logp[:Lc, sl],
+                            src=self.src[:Lc, sl], valid=self.valid[:Lc, sl], lens=self.lens[sl], w_ep=self.w_ep[sl], key=self.key[sl],
+                            lens_host=self.lens_host[sl])
 
-def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base: int = 0, seed: int = 0, epoch: int = 0) -> EpisodeBatch:
-    """[T, N, ...] time-major columns -> EpisodeBatch.  cut [T, N] closes an episode (terminal, timeout or epoch end)."""
+
+def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base: int = 0, seed: int = 0, epoch: int = 0,
+                  sort_by_length: bool = False) -> EpisodeBatch:
+    """[T, N, ...] time-major columns -> EpisodeBatch.  cut [T, N] closes an episode (terminal, timeout or epoch end).
+    sort_by_length: episodes in descending length (stable) instead of (env, order in the env); every episode keeps its weight and
+    its draw key, so the update is the same sum in another order."""
     T, N = cut.shape
     dev = cut.device
     c = cut.long()
@@ -266,8 +281,13 @@ def pack_episodes(obs, act, adv, ret, logp, src, cut, n_total: int, env_id_base:
     w_ep = 1.0 / (float(n_total) * n_ep[env_of].float())
     k_of = torch.arange(E, device=dev) - off[env_of]
     key = hash_uniform(((env_of + int(env_id_base)) * 4096 + k_of) ^ _s64((int(seed) * 0x2545F4914F6CDD1D) ^ (int(epoch) * 0x9E3779B97F4A7C15))).mul(2.0 ** 52).long()
-    return EpisodeBatch(X=scat(obs), act=scat(act), adv=scat(adv), ret=scat(ret), logp=scat(logp), src=scat(src), valid=valid,
-                        lens=lens, w_ep=w_ep, key=key)
+    B = EpisodeBatch(X=scat(obs), act=scat(act), adv=scat(adv), ret=scat(ret), logp=scat(logp), src=scat(src), valid=valid,
+                     lens=lens, w_ep=w_ep, key=key)
+    if sort_by_length:
+        order = torch.argsort(lens, descending=True, stable=True)
+        B = EpisodeBatch(X=B.X[:, order], act=B.act[:, order], adv=B.adv[:, order], ret=B.ret[:, order], logp=B.logp[:, order],
+                         src=B.src[:, order], valid=B.valid[:, order], lens=lens[order], w_ep=w_ep[order], key=key[order])
+    return B
 
 
 # ------------------------------------------------------------------------------------------------ K13 plumbing
@@ -387,7 +407,7 @@ class RNNAgentPPO:
                 parts.append(cell.particle_predictions(h))                        # particle_pred[zz] (ppo.py:1079)
         return torch.stack(locs), (torch.stack(parts) if want_particles else None)
 
-    def _pfgru_pass_hip(self, X: torch.Tensor, draws: "HashDraws") -> torch.Tensor:
+    def _pfgru_pass_hip(self, X: torch.Tensor, draws: "HashDraws", lens_host: Optional[List[int]] = None) -> torch.Tensor:
         """The no-grad PFGRU pass of grad_step (:555-558) on K11: X [L, E, 11] -> loc [L, E, 2].  Particle sets start from the
         reset kernel's hash draws and are carried; the draw keys are the chunk's episode keys."""
         from .pfgru import pack_weights
@@ -401,13 +421,18 @@ class RNNAgentPPO:
         episode = torch.ones(E, dtype=torch.int64, device=dev)
         calls = torch.zeros(E, dtype=torch.int64, device=dev)
         wts = pack_weights([self.agent.model])
-        loc = torch.empty(L, E, 2, dtype=torch.float32, device=dev)
+        loc = torch.zeros(L, E, 2, dtype=torch.float32, device=dev)
+        # episodes sorted by descending length: the ones still running at step t are a prefix, the launch covers only those
+        alive = [E] * L
+        if lens_host is not None and all(a >= b for a, b in zip(lens_host, lens_host[1:])):
+            asc = lens_host[::-1]
+            alive = [E - bisect.bisect_right(asc, t) for t in range(L)]
         _lib.check(lib.rs_pfgru_reset(h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(), None, E, 1, st),
                    "rs_pfgru_reset")
         Xc = X.contiguous()
         for t in range(L):
             _lib.check(lib.rs_pfgru_step(wts.data_ptr(), Xc[t].data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(),
-                                         calls.data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), E, 1, st),
+                                         calls.data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), alive[t], 1, st),
                        "rs_pfgru_step")
             calls.add_(1)
         return loc
@@ -415,6 +440,7 @@ class RNNAgentPPO:
     def model_loss(self, B: EpisodeBatch, sl: slice, draws) -> torch.Tensor:
         """Sum over the chunk's episodes of w_ep x total_loss (ppo.py:1062-1128)."""
         a = self.bp_args
+        B, sl = B.chunk(sl), slice(None)
         X3, valid, lens = B.X[:, sl, :3], B.valid[:, sl], B.lens[sl]
         L = X3.shape[0]
         tar = B.src[:, sl] / a.area_scale                                          # :1067 (padded rows: weight 0)
@@ -441,6 +467,7 @@ class RNNAgentPPO:
         """model_loss + backward for an episode chunk on K13 (rs_pfgru_train): returns (loss, summed gradient slab, idx [L, E, 40])."""
         a = self.bp_args
         dev = self.device
+        B, sl = B.chunk(sl), slice(None)
         X = B.X[:, sl].contiguous()
         L, E = X.shape[0], X.shape[1]
         valid, lens = B.valid[:, sl], B.lens[sl].contiguous()
@@ -476,7 +503,7 @@ class RNNAgentPPO:
                 if draws_for is not None:
                     d = draws_for(it, sl)
                 elif self.device.type == "cuda":
-                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.X.shape[0])
+                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0])
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it)
                 if isinstance(d, KernelDraws) and getattr(self, "use_k13", True):
@@ -503,12 +530,13 @@ class RNNAgentPPO:
         """grad_step (:550-566) + the per-episode loss of update_rada2c (ppo.py:1191-1234) for an episode chunk.
         Returns (loss to back-propagate, stats [kl, ent, clipfrac, val_loss, loss, sum w (h loc - src)^2, sum w])."""
         ac = self.agent
+        B, sl = B.chunk(sl), slice(None)
         X, valid = B.X[:, sl], B.valid[:, sl]
         w = B.w[:, sl]
         L, E = X.shape[0], X.shape[1]
         with torch.no_grad():
             if isinstance(draws, HashDraws) and X.is_cuda:
-                loc = self._pfgru_pass_hip(X, draws)          # K11 with carried particle sets: one launch per step
+                loc = self._pfgru_pass_hip(X, draws, B.lens_host)          # K11 with carried particle sets: one launch per step
             else:
                 loc, _ = self._pfgru_pass(X[..., :3], draws, False)
         h = draws.gru_h0() if hasattr(draws, "gru_h0") else ac.gru_h0(draws.gru_h0_u())
@@ -750,7 +778,7 @@ class RNNCollector:
             adv = normalize_advantages(buf.adv[:, :, a])
             B = pack_episodes(buf.obs[:, :, a], buf.act[:, :, a], adv, buf.ret[:, :, a], buf.logp[:, :, a], buf.source_tar, cut,
                               n_total=self.N * _world(), env_id_base=int(self.env.cfg.env_id_base), seed=int(self.env.cfg.seed) + 7919 * a,
-                              epoch=self.epoch)
+                              epoch=self.epoch, sort_by_length=True)
             out[a] = ag.update_agent(B)
         self.epoch += 1
         return out

@@ -130,3 +130,30 @@ def test_hash_draw_update_runs_and_is_deterministic():
         assert np.isfinite([r.loss_policy, r.loss_critic, r.loss_predictor, r.kl_divergence, r.LocLoss]).all() and 1 <= r.stop_iteration <= 3
         outs.append(torch.cat([p.detach().reshape(-1) for p in ag.agent.parameters()]))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_sorted_episode_batch_gives_the_same_update():
+    """pack_episodes(sort_by_length=True) + per-chunk trimming (what the collector hands to update_agent) is the same sum of
+    per-episode losses in another order: losses, statistics and parameters after an update agree with the unsorted batch."""
+    rng = np.random.default_rng(11)
+    T, N = 30, 12
+    f = lambda a: torch.from_numpy(np.asarray(a))
+    cols = (f(rng.random((T, N, 11), dtype=np.float32)), f(rng.integers(0, 8, (T, N))), f(rng.normal(size=(T, N)).astype(np.float32)),
+            f(rng.normal(size=(T, N)).astype(np.float32)), f((np.log(1 / 8) + 0.05 * rng.normal(size=(T, N))).astype(np.float32)),
+            f((rng.random((T, N, 2)) * 2000 + 200).astype(np.float32)))
+    cut = rng.random((T, N)) < 0.12
+    cut[-1] = True
+    outs = []
+    for srt in (False, True):
+        B = pack_episodes(*cols, f(cut.astype(np.uint8)), n_total=N, seed=5, epoch=2, sort_by_length=srt)
+        if srt:
+            ls = B.lens.tolist()
+            assert ls == sorted(ls, reverse=True) and B.chunk(slice(len(ls) // 2, len(ls))).X.shape[0] == ls[len(ls) // 2]
+        torch.manual_seed(3)
+        ag = RNNAgentPPO(id=0, seed=1, device="cpu", train_pi_iters=2, train_pfgru_iters=2, episode_chunk=7)
+        r = ag.update_agent(B)
+        outs.append((r, torch.cat([p.detach().reshape(-1) for p in ag.agent.parameters()])))
+    a, b = outs
+    for k in ("loss_policy", "loss_critic", "loss_predictor", "kl_divergence", "Entropy", "LocLoss"):
+        assert np.isclose(getattr(a[0], k), getattr(b[0], k), rtol=2e-4, atol=1e-6), (k, getattr(a[0], k), getattr(b[0], k))
+    assert float((a[1] - b[1]).abs().max()) <= 2.5e-3            # Adam steps of lr <= 5e-3: same direction everywhere
