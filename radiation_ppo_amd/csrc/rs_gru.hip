@@ -12,7 +12,7 @@
 // (backward) product whose weights are wave-uniform and arrive through the scalar unit (s_load_dwordx16 -> SGPR operand of
 // v_fma), exactly as in K11 (rs_pfgru.hip) -- including its two remedies for the scalar-weight code generation (row blocks
 // closed by a scheduling barrier, results pinned).  The chain is 120 steps of ~1 900 dependent-ish FMAs per lane: latency
-// bound (E / 64 waves), ~1 ms per pass at 4 400 episodes, against ~45 ms for the library GRU's per-step launches.
+// bound (E / 64 waves), against ~45 ms for the library GRU's per-step launches.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -26,65 +26,93 @@ constexpr int G3 = 3 * GH;                   // 72
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 
-// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16), one k row per block
+// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16): one k row per
+// s_load_dwordx16, rows requested two ahead, every row closed by a scheduling barrier with the accumulators pinned (otherwise the
+// loads are hoisted to the top of the step, spilled to VGPR lanes and read back one v_readlane per FMA operand: 4 658 of them in
+// the forward step, half its time)
 template <int K, int OUTP, typename F>
 __device__ __forceinline__ void gru_matvec(cmem_t W, F cval, float (&out)[OUTP]) {
 #pragma unroll
     for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wa[16], wb[16];
+        float acc[16], wq[3][16];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wa[o] = W[16 * ch + o]; }
+        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wq[0][o] = W[16 * ch + o]; wq[1][o] = W[OUTP + 16 * ch + o]; }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k + 1 < K) {
+            if (k + 2 < K) {
 #pragma unroll
-                for (int o = 0; o < 16; ++o) wb[o] = W[(k + 1) * OUTP + 16 * ch + o];
+                for (int o = 0; o < 16; ++o) wq[(k + 2) % 3][o] = W[(k + 2) * OUTP + 16 * ch + o];
             }
             const float c = cval(k);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[o], c, acc[o]);
-            if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % 3][o], c, acc[o]);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) wa[o] = wb[o];
+            for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            asm volatile("" : "+v"(acc[o]));
-            out[16 * ch + o] = acc[o];
-        }
+        for (int o = 0; o < 16; ++o) out[16 * ch + o] = acc[o];
     }
 }
 
-__device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each), branch free
+__device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x)); }
+
+template <int N>
+__device__ __forceinline__ void ld_row(const float* __restrict__ src, float (&dst)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; u += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + u);
+        dst[u] = v.x; dst[u + 1] = v.y; dst[u + 2] = v.z; dst[u + 3] = v.w;
+    }
+}
+template <int N>
+__device__ __forceinline__ void st_row(float* __restrict__ dst, const float (&src)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; u += 4) *reinterpret_cast<float4*>(dst + u) = make_float4(src[u], src[u + 1], src[u + 2], src[u + 3]);
+}
 
 // forward: gi [L][E][72], h0 [E][24], whh_t [24][80] (k-major W_hh^T, columns 72..79 zero), bhh [80]
 //          -> hs [L][E][24] (h_t), gates [L][E][96] = r | z | n | (W_hn h + b_hn)
+// A step's rows are read and written as whole float4 rows, the next step's gi row is requested before this step's product: the
+// first version loaded three words and stored five per hidden unit behind one another (24 memory round trips per step: 18 us
+// per step, all of it waiting).
 __global__ void __launch_bounds__(64) rs_gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ h0, const float* __restrict__ whh_t,
                                                         const float* __restrict__ bhh, float* __restrict__ hs, float* __restrict__ gates,
                                                         int L, int E) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     const int ec = e < E ? e : E - 1;                      // idle lanes shadow the last episode, store nothing
-    const cmem_t W = as_cmem(whh_t), B = as_cmem(bhh);
-    float h[GH];
-#pragma unroll
-    for (int j = 0; j < GH; ++j) h[j] = h0[(size_t)ec * GH + j];
+    float h[GH], g[G3];
+    ld_row(h0 + (size_t)ec * GH, h);
+    ld_row(gi + (size_t)ec * G3, g);
     for (int t = 0; t < L; ++t) {
+        const float* wp = whh_t; asm volatile("" : "+s"(wp));                 // per step: keeps LICM from hoisting (and spilling) the rows
+        const float* bp = bhh; asm volatile("" : "+s"(bp));
+        const cmem_t W = as_cmem(wp), B = as_cmem(bp);
+        float gn[G3];
+        if (t + 1 < L) ld_row(gi + ((size_t)(t + 1) * E + ec) * G3, gn);
         float gh[80];
 #pragma unroll
         for (int o = 0; o < 80; ++o) gh[o] = B[o];
         gru_matvec<GH, 80>(W, [&](int k) -> float { return h[k]; }, gh);
-        const float* g = gi + ((size_t)t * E + ec) * G3;
-        float* go = gates + ((size_t)t * E + ec) * (4 * GH);
-        float* ho = hs + ((size_t)t * E + ec) * GH;
+        float go[4 * GH];
 #pragma unroll
         for (int j = 0; j < GH; ++j) {
             const float r = gru_sigmoid(g[j] + gh[j]);
             const float z = gru_sigmoid(g[GH + j] + gh[GH + j]);
             const float hn = gh[2 * GH + j];
-            const float n = tanhf(g[2 * GH + j] + r * hn);
-            const float hv = (1.0f - z) * n + z * h[j];
-            if (e < E) { go[j] = r; go[GH + j] = z; go[2 * GH + j] = n; go[3 * GH + j] = hn; ho[j] = hv; }
-            h[j] = hv;
+            const float n = gru_tanh(g[2 * GH + j] + r * hn);
+            h[j] = (1.0f - z) * n + z * h[j];
+            go[j] = r; go[GH + j] = z; go[2 * GH + j] = n; go[3 * GH + j] = hn;
+        }
+        if (e < E) {
+            st_row(gates + ((size_t)t * E + ec) * (4 * GH), go);
+            st_row(hs + ((size_t)t * E + ec) * GH, h);
+        }
+        if (t + 1 < L) {
+#pragma unroll
+            for (int u = 0; u < G3; ++u) g[u] = gn[u];
         }
     }
 }
@@ -96,35 +124,51 @@ __global__ void __launch_bounds__(64) rs_gru_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ dgh, int L, int E) {
     const int e = blockIdx.x * 64 + threadIdx.x;
     const int ec = e < E ? e : E - 1;
-    const cmem_t W = as_cmem(whh);
     float dh[GH];
 #pragma unroll
     for (int j = 0; j < GH; ++j) dh[j] = 0.0f;
-    for (int t = L - 1; t >= 0; --t) {
+    float dx[GH], go[4 * GH], hp[GH];                     // the step's rows: dL/dh_t from the heads, gates, h_{t-1}
+    auto load_step = [&](int t, float (&a)[GH], float (&b)[4 * GH], float (&c)[GH]) {
         const size_t te = (size_t)t * E + ec;
-        const float* go = gates + te * (4 * GH);
-        const float* hp = (t > 0) ? hs + ((size_t)(t - 1) * E + ec) * GH : h0 + (size_t)ec * GH;
-        float dg[G3];                                     // dL/d(gh): [dr | dz | dn * r]
+        ld_row(dhs + te * GH, a);
+        ld_row(gates + te * (4 * GH), b);
+        ld_row(t > 0 ? hs + (te - E) * GH : h0 + (size_t)ec * GH, c);
+    };
+    load_step(L - 1, dx, go, hp);
+    for (int t = L - 1; t >= 0; --t) {
+        const float* wp = whh; asm volatile("" : "+s"(wp));
+        const cmem_t W = as_cmem(wp);
+        const size_t te = (size_t)t * E + ec;
+        float dxn[GH], gon[4 * GH], hpn[GH];
+        if (t > 0) load_step(t - 1, dxn, gon, hpn);        // requested before this step's arithmetic
+        float dg[G3], di[G3];                              // dL/d(gh) = [dr | dz | dn * r], dL/d(gi) = [dr | dz | dn]
         float nxt[32];
 #pragma unroll
         for (int j = 0; j < GH; ++j) {
-            const float d = dh[j] + dhs[te * GH + j];
+            const float d = dh[j] + dx[j];
             const float r = go[j], z = go[GH + j], n = go[2 * GH + j], hn = go[3 * GH + j];
             const float dn = d * (1.0f - z) * (1.0f - n * n);
             const float dz = d * (hp[j] - n) * z * (1.0f - z);
             const float dr = dn * hn * r * (1.0f - r);
             dg[j] = dr; dg[GH + j] = dz; dg[2 * GH + j] = dn * r;
-            if (e < E) {
-                dgi[te * G3 + j] = dr; dgi[te * G3 + GH + j] = dz; dgi[te * G3 + 2 * GH + j] = dn;
-                dgh[te * G3 + j] = dr; dgh[te * G3 + GH + j] = dz; dgh[te * G3 + 2 * GH + j] = dn * r;
-            }
+            di[j] = dr; di[GH + j] = dz; di[2 * GH + j] = dn;
             nxt[j] = d * z;                               // the direct path h_{t-1} -> h_t
+        }
+        if (e < E) {
+            st_row(dgi + te * G3, di);
+            st_row(dgh + te * G3, dg);
         }
 #pragma unroll
         for (int j = GH; j < 32; ++j) nxt[j] = 0.0f;
         gru_matvec<G3, 32>(W, [&](int k) -> float { return dg[k]; }, nxt);       // + W_hh^T dgh
 #pragma unroll
         for (int j = 0; j < GH; ++j) dh[j] = nxt[j];
+        if (t > 0) {
+#pragma unroll
+            for (int j = 0; j < GH; ++j) { dx[j] = dxn[j]; hp[j] = hpn[j]; }
+#pragma unroll
+            for (int j = 0; j < 4 * GH; ++j) go[j] = gon[j];
+        }
     }
 }
 

@@ -54,6 +54,37 @@ class _SeqPt(nn.Module):
         self.Valms = nn.Sequential(nn.Linear(hid, val), nn.Tanh(), nn.Linear(val, 1))         # (:367-368)
 
 
+class _LinearRows(torch.autograd.Function):
+    """y = x W^T + b for a tall x [S, in] with the weight gradient reduced in two steps (batched partial products over 1024-row
+    slabs, then a sum): autograd's own g^T @ x is a 32 x 24 GEMM with a reduction length of L * E ~ 5e5, which the BLAS library runs
+    30x slower than its memory time (the MT32x32x256 / MT32x16x512 kernels: 3.1 of a policy pass's 15 ms; maps._LinearTall)."""
+    SLAB = 1024
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        R = _LinearRows.SLAB
+        m = (x.shape[0] // R) * R
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(g[:m].view(m // R, R, -1).transpose(1, 2), x[:m].view(m // R, R, -1)).sum(dim=0) + g[m:].t() @ x[m:]
+        gb = g.sum(dim=0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _seq(net: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    tall = x.is_cuda and x.dim() == 2 and x.shape[0] >= 65536 and torch.is_grad_enabled()
+    for layer in net:
+        x = _LinearRows.apply(x, layer.weight, layer.bias) if tall and isinstance(layer, nn.Linear) else layer(x)
+    return x
+
+
 class _RecurrentNet(nn.Module):
     def __init__(self, *a):
         super().__init__()
@@ -92,7 +123,7 @@ class RNNModelActorCritic(nn.Module):
 
     def heads(self, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         v = self.pi.logits_net.v_net
-        return v.Woms(h), v.Valms(h).squeeze(-1)
+        return _seq(v.Woms, h), _seq(v.Valms, h).squeeze(-1)
 
     def policy_step(self, obs: torch.Tensor, loc_pred: torch.Tensor, h: torch.Tensor):
         """step (:528-548) after the PFGRU: logits [B, 8], value [B], new GRU state [B, hid]."""
