@@ -363,6 +363,43 @@ def run_config4(dev, iters: int = 1, warmup: int = 1):
     return out
 
 
+def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
+    """SURVEY section 8 row f2 (not a BASELINE config): the reference's original single-agent RAD-A2C -- GRU actor-critic + PFGRU
+    location predictor, 15 PFGRU + <= 40 policy iterations over whole episodes per epoch."""
+    import torch
+    from radiation_ppo_amd import _lib
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
+    N, T, L = 1024, T_EPOCH, L_EPISODE
+    torch.manual_seed(SEED % (2 ** 31))
+    torch.cuda.reset_peak_memory_stats(dev)
+    env = RadSearchVec(N, number_agents=1, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED, device=dev)
+    ag = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, seed=2, device=dev)}
+    col = RNNCollector(env, ag, T, L)
+    for _ in range(warmup):
+        col.collect(); col.update()
+    torch.cuda.synchronize()
+    tc = tu = 0.0
+    stops = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        a = time.perf_counter(); col.collect(); torch.cuda.synchronize(); b = time.perf_counter()
+        res = col.update(); torch.cuda.synchronize(); c = time.perf_counter()
+        tc += b - a; tu += c - b
+        stops.append(res[0].stop_iteration)
+    dt = time.perf_counter() - t0
+    out = {"workload": "single-agent RAD-A2C (GRU(13->24) actor-critic + PFGRU predictor, 40 particles), U{1..5} random rectangles, "
+                       "1024 envs, 480 steps/epoch; step = 1 PPO iteration (rollout + 15 PFGRU iterations (K13) + <=40 policy iterations "
+                       "through K11 / K12)",
+           "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
+           "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
+           "policy_iterations": stops, "pfgru_iterations": ag[0].train_pfgru_iters, "env_error_flags": env.error_flags(),
+           "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    del col, env, ag
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -374,7 +411,7 @@ def main():
                     help="weak: 4096 envs per GPU (default); strong: 4096 envs in total (SURVEY 8d Metric 2)")
     ap.add_argument("--collector", choices=["fused", "torch"], default="fused")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional tests)")
-    ap.add_argument("--configs", default=None, help="comma list of extra BASELINE configs to run at N=1 (default '3,4'; 'none')")
+    ap.add_argument("--configs", default=None, help="comma list of extra BASELINE configs to run at N=1 (default '3,4,a2c': BASELINE configs 3 and 4 and the RAD-A2C row f2; 'none')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -526,15 +563,16 @@ def main():
                 del big
             except Exception as e:  # noqa: BLE001
                 result["roofline_env_step_large_n"] = {"error": repr(e)}
-            which = args.configs if args.configs is not None else ("3,4" if N == ENVS_PER_GPU else "none")
+            which = args.configs if args.configs is not None else ("3,4,a2c" if N == ENVS_PER_GPU else "none")
             extra = {}
             del col, env
             torch.cuda.empty_cache()
             for c in [x.strip() for x in which.split(",") if x.strip() and x.strip() != "none"]:
+                key = "row_f2_rada2c" if c == "a2c" else f"config{c}"
                 try:
-                    extra[f"config{c}"] = {"3": run_config3, "4": run_config4}[c](dev)
+                    extra[key] = {"3": run_config3, "4": run_config4, "a2c": run_config_a2c}[c](dev)
                 except Exception as e:  # noqa: BLE001
-                    extra[f"config{c}"] = {"error": repr(e)}
+                    extra[key] = {"error": repr(e)}
             if extra:
                 result["configs"] = extra
             if not args.no_cpu_baseline:
