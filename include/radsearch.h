@@ -366,6 +366,17 @@ int rs_gru_forward(const float* gi, const float* h0, const float* whh_t, const f
 int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const float* h0, const float* whh, float* dgi, float* dgh,
                     int32_t steps, int32_t episodes, rs_stream_t stream);
 
+/* One step of the RAD-A2C actor-critic behind the PFGRU, for every env (RNNModelActorCritic.step after the location prediction,
+ * NeuralNetworkCores/RADA2C_core.py:528-548): h' = GRU(cat(x, loc), h) (SeqPt.forward :377-381), logits = Woms(h') (:363-366),
+ * value = Valms(h') (:367-368), action by inverse CDF of softmax(logits) on the caller's uniform u (Categorical.sample :541-544 --
+ * documented RNG deviation), logp = log_softmax(logits)[action].
+ *   weights [RS_RNN_POLICY_WEIGHT_FLOATS]  packed parameters (layout: csrc/rs_rnn_policy.hip; packer: rada2c.py)
+ *   x [N][11], loc [N][2], h [N][24];  u [N] (needed when act / logp are wanted)
+ *   outputs, any may be NULL: h_out [N][24] (may alias h), logits [N][8], value [N], act [N] int64, logp [N] */
+#define RS_RNN_POLICY_WEIGHT_FLOATS 5296
+int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
+                       float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

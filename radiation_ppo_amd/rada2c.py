@@ -350,6 +350,24 @@ def pack_train_weights(cell) -> torch.Tensor:
     return w
 
 
+PF_POLICY_WEIGHT_FLOATS = 5296                                       # include/radsearch.h: RS_RNN_POLICY_WEIGHT_FLOATS
+
+
+def pack_policy_weights(ac: "RNNModelActorCritic") -> torch.Tensor:
+    """GRU + head parameters in the layout rs_rnn_policy_step reads (csrc/rs_rnn_policy.hip): every block k-major, padded to 16."""
+    v = ac.pi.logits_net.v_net
+    g = v.seq_model
+    assert ac.hid == 24 and g.weight_ih_l0.shape == (72, 13) and v.Woms[0].out_features == 32 and v.Valms[0].out_features == 32 \
+        and v.Woms[2].out_features == 8, "rs_rnn_policy_step is built for GRU(13, 24) with 32-unit heads and 8 actions"
+    parts = [F.pad(g.weight_ih_l0.t(), (0, 8)), F.pad(g.bias_ih_l0, (0, 8)), F.pad(g.weight_hh_l0.t(), (0, 8)), F.pad(g.bias_hh_l0, (0, 8)),
+             v.Woms[0].weight.t(), v.Woms[0].bias, v.Valms[0].weight.t(), v.Valms[0].bias,
+             F.pad(v.Woms[2].weight.t(), (0, 8)), F.pad(v.Woms[2].bias, (0, 8)),
+             F.pad(torch.cat([v.Valms[2].weight.reshape(-1), v.Valms[2].bias.reshape(-1)]), (0, 15))]
+    w = torch.cat([p.reshape(-1) for p in parts]).float().contiguous()
+    assert w.numel() == PF_POLICY_WEIGHT_FLOATS
+    return w
+
+
 def unpack_train_grads(cell, g: torch.Tensor) -> Dict[str, torch.Tensor]:
     """A summed gradient slab [PF_TRAIN_GRAD_FLOATS] -> gradients by parameter name (PFGRUCell.named_parameters)."""
     zr = g[:48 * 28].view(48, 28)
@@ -402,6 +420,30 @@ class RNNAgentPPO:
         self.pfgru_scheduler = torch.optim.lr_scheduler.StepLR(self.model_optimizer, step_size=100, gamma=0.99)
         self.epochs_done = 0
         self.agent.eval()
+
+    def policy_weights(self) -> torch.Tensor:
+        """The GRU + head parameters packed for K14, re-packed IN PLACE when a parameter changed (a captured collector step keeps
+        reading the same buffer)."""
+        ver = tuple(p._version for p in self.agent.pi.parameters())
+        if getattr(self, "_polw_ver", None) != ver:
+            with torch.no_grad():
+                w = pack_policy_weights(self.agent)
+                if getattr(self, "_polw", None) is None:
+                    self._polw = w
+                else:
+                    self._polw.copy_(w)
+            self._polw_ver = ver
+        return self._polw
+
+    def policy_step_hip(self, x, loc, h, u=None, h_out=None, logits=None, value=None, act=None, logp=None, weights=None) -> None:
+        """RNNModelActorCritic.step behind the PFGRU on K14 (rs_rnn_policy_step); outputs are written to the tensors given."""
+        w = self.policy_weights() if weights is None else weights
+        ptr = lambda t: None if t is None else t.data_ptr()
+        for t in (x, loc, h, u, h_out, logits, value, act, logp):
+            assert t is None or (t.is_cuda and t.is_contiguous())
+        _lib.check(_lib.load().rs_rnn_policy_step(w.data_ptr(), x.data_ptr(), loc.data_ptr(), h.data_ptr(), ptr(u), ptr(h_out), ptr(logits),
+                                                  ptr(value), ptr(act), ptr(logp), x.shape[0],
+                                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "rs_rnn_policy_step")
 
     def reduce_pfgru_training(self) -> None:
         """ppo.py:685-689."""
@@ -689,6 +731,10 @@ class RNNCollector:
         self._row_act = torch.zeros(self.N, self.A, dtype=torch.int64, device=dev)
         self._row_f = torch.zeros(3, self.N, self.A, dtype=torch.float32, device=dev)
         self._src = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
+        # K14 (rs_rnn_policy_step): GRU cell + heads + draw in one launch instead of ~35 library kernels per call
+        self.use_k14 = torch.device(dev).type == "cuda" and all(ag.agent.hid == 24 for ag in agents.values())
+        self._k_act = torch.zeros(self.A, self.N, dtype=torch.int64, device=dev)
+        self._k_f = torch.zeros(self.A, 3, self.N, dtype=torch.float32, device=dev)          # logp, value, bootstrap value
         self.obs = None
         self.started = False
         self.epoch = 0
@@ -724,6 +770,15 @@ class RNNCollector:
         env.action_uniforms(self._u)
         loc = self.bank.predict(x)                                            # PFGRU (K11), carried particle sets
         for a, ag in self.agents.items():
+            if self.use_k14:
+                act = self._k_act[a]
+                ag.policy_step_hip(x[:, a].contiguous(), loc[:, a].contiguous(), self.h[a], u=self._u[:, a].contiguous(), h_out=self.h[a],
+                                   value=self._k_f[a, 1], act=act, logp=self._k_f[a, 0])
+                self._row_act[:, a] = act
+                self._row_f[0, :, a] = self._k_f[a, 0]
+                self._row_f[1, :, a] = self._k_f[a, 1]
+                self._act8[:, a] = act.to(torch.int8)
+                continue
             logits, v, h1 = ag.agent.policy_step(x[:, a], loc[:, a], self.h[a])
             self.h[a] = h1
             logp_all = torch.log_softmax(logits, dim=-1)
@@ -754,7 +809,11 @@ class RNNCollector:
         xb = self._x(self.obs)
         locb = self.bank.predict(xb, mask=boot)
         for a, ag in self.agents.items():
-            _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
+            if self.use_k14:
+                vb = self._k_f[a, 2]
+                ag.policy_step_hip(xb[:, a].contiguous(), locb[:, a].contiguous(), self.h[a], value=vb)
+            else:
+                _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
             self._row_f[2, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
         put(buf.last_val, self._row_f[2])
         acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
@@ -779,6 +838,9 @@ class RNNCollector:
         self._acc.zero_()
         self._t.zero_()
         self._reset_hidden(None)                                              # train.py:322-329: every epoch starts fresh
+        if self.use_k14:
+            for ag in self.agents.values():
+                ag.policy_weights()                                           # re-packed in place after an update
         if self.use_graph and self._graph is None and T > 1:
             side = torch.cuda.Stream(device=self.env.device)                  # library warm-up (GEMM handles) outside the capture
             side.wait_stream(torch.cuda.current_stream(self.env.device))

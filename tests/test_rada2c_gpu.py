@@ -310,3 +310,43 @@ def test_update_model_on_k13_equals_autograd_path():
     for k in res[0][1]:
         d = float((res[0][1][k] - res[1][1][k]).abs().max())
         assert d <= 0.25 * lr, (k, d)                                    # an Adam step moves every element by ~lr: same direction everywhere
+
+
+def test_policy_step_kernel_matches_torch_composition():
+    """K14 (rs_rnn_policy_step: GRU cell + heads + inverse-CDF draw in one launch) against RNNModelActorCritic.policy_step and the
+    collector's torch sampling: new state, logits, value, action, log-probability; in-place state update; re-packing after a
+    parameter change."""
+    from radiation_ppo_amd.rada2c import RNNAgentPPO
+    torch.manual_seed(12)
+    ag = RNNAgentPPO(id=0, seed=1)
+    with torch.no_grad():
+        for p in ag.agent.pi.parameters():
+            p.mul_(1.7)
+    N = 1000                                                             # not a multiple of 64
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, 11, generator=g).cuda()
+    loc = torch.rand(N, 2, generator=g).cuda()
+    h = (torch.rand(N, 24, generator=g) * 0.4 - 0.2).cuda()
+    u = torch.rand(N, generator=g).cuda()
+    for rep in range(2):
+        with torch.no_grad():
+            logits_t, v_t, h_t = ag.agent.policy_step(x, loc, h)
+            lp_all = torch.log_softmax(logits_t, dim=-1)
+            cdf = torch.cumsum(lp_all.exp(), dim=-1)
+            act_t = (cdf[:, :-1] <= u.unsqueeze(-1)).sum(dim=-1)
+        hk = h.clone()
+        logits = torch.empty(N, 8, device="cuda"); v = torch.empty(N, device="cuda"); lp = torch.empty(N, device="cuda")
+        act = torch.empty(N, dtype=torch.int64, device="cuda")
+        ag.policy_step_hip(x, loc, hk, u=u, h_out=hk, logits=logits, value=v, act=act, logp=lp)
+        assert torch.allclose(hk, h_t, rtol=1e-5, atol=2e-6), float((hk - h_t).abs().max())
+        assert torch.allclose(logits, logits_t, rtol=1e-5, atol=5e-6) and torch.allclose(v, v_t, rtol=1e-5, atol=5e-6)
+        edge = (cdf[:, :-1] - u.unsqueeze(-1)).abs().amin(dim=1) < 1e-5   # a uniform within rounding of a CDF step may fall either side
+        assert bool(((act == act_t) | edge).all()) and int((act != act_t).sum()) <= 2
+        same = act == act_t
+        assert torch.allclose(lp[same], lp_all.gather(-1, act_t.unsqueeze(-1)).squeeze(-1)[same], rtol=1e-5, atol=5e-6)
+        vb = torch.empty(N, device="cuda")
+        ag.policy_step_hip(x, loc, h, value=vb)                          # the bootstrap form: value only, state untouched
+        assert torch.allclose(vb, v_t, rtol=1e-5, atol=5e-6)
+        with torch.no_grad():                                            # an optimiser step bumps the versions: the pack follows
+            for p in ag.agent.pi.parameters():
+                p.add_(0.01)
