@@ -41,6 +41,26 @@ if mode == "cnn":
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(0)
+if mode == "rnn":
+    # RAD-A2C (row f2): GRU actor-critic + PFGRU on the product kernels (K11 - K14), envs sharded over ranks
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector    # noqa: E402
+    N, T, L = total_envs // world, 36, 12
+    torch.manual_seed(99)
+    env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)
+    agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, alpha=0.1, train_pi_iters=3, train_pfgru_iters=2, seed=5,
+                             episode_chunk=16)}
+    agents[0].sync_params()
+    col = RNNCollector(env, agents, T, L)
+    col.collect()
+    res = col.update()[0]
+    if rank == 0:
+        flat = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()]).cpu()
+        torch.save({"params": flat, "kl": res.kl_divergence, "loss": res.loss_policy, "stop": res.stop_iteration,
+                    "entropy": res.Entropy, "loss_critic": res.loss_critic, "loss_predictor": res.loss_predictor}, out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0)
 N, T, L = total_envs // world, 48, 12
 torch.manual_seed(1234)                                              # same initial policy on every rank / world size
 env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=77, env_id_base=rank * N)

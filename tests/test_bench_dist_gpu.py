@@ -105,3 +105,26 @@ def test_data_parallel_cnn_equals_single_process(tmp_path):
     assert a["stop"] == b["stop"]
     assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["loss_critic"] - b["loss_critic"]) < 1e-5
     assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=3e-5), float((a["params"] - b["params"]).abs().max())
+
+
+def test_data_parallel_rada2c_equals_single_process(tmp_path):
+    """The same for RAD-A2C (row f2) on the product kernels: 2 ranks x 8 envs == 1 process x 16 envs after one PPO iteration
+    (collector with K11 / K14, PFGRU iterations on K13, policy iterations through K11 / K12; gradient and statistics all-reduce)."""
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "_dp_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    r1 = subprocess.run([sys.executable, worker, one, "16", "rnn"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29753", worker, two, "16", "rnn"], cwd=ROOT, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = torch.load(one), torch.load(two)
+    assert a["stop"] == b["stop"]
+    for k in ("kl", "loss", "loss_critic", "entropy", "loss_predictor"):
+        assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    # Adam amplifies float32 summation-order noise on near-zero gradients up to one step (lr 5e-3 for the PFGRU, 3e-4 for pi):
+    # everything must stay within a fraction of a step, most elements far closer
+    d = (a["params"] - b["params"]).abs()
+    assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 0.05, (float(d.max()), float((d > 2e-5).float().mean()))
