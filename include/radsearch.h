@@ -377,6 +377,20 @@ int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
 
+/* ---- running observation statistics ------------------------------------------------------------
+ * StatisticStandardization.update / standardize / reset (NeuralNetworkCores/RADTEAM_core.py:188-277) for num_envs x num_agents
+ * independent streams, float64 state count / mean / sq (square_dist_mean) / std, one pass each:
+ *   update      : streams of the envs with mask[n] != 0 (all when NULL) take the reading reading[i * stride], i = n * A + a
+ *                 (Welford; the first sample sets the mean only; std = max(sqrt(sq / (count - 1)), 1))
+ *   reset       : count = mean = sq = 0, std = 1 for the masked envs
+ *   standardize : out[i * out_stride] = (float)((reading[i * stride] - mean[i]) / std[i]) */
+int rs_welford_update(double* count, double* mean, double* sq, double* std, const float* reading, int64_t stride, const uint8_t* mask,
+                      int32_t num_envs, int32_t num_agents, rs_stream_t stream);
+int rs_welford_reset(double* count, double* mean, double* sq, double* std, const uint8_t* mask, int32_t num_envs, int32_t num_agents,
+                     rs_stream_t stream);
+int rs_welford_standardize(const double* mean, const double* std, const float* reading, int64_t stride, float* out, int64_t out_stride,
+                           int32_t streams, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,9 +131,12 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
         hid = agent.agent.gru_h0(hash_uniform(gk))
     for _ in range(L):
         x = obs.clone()
-        x[..., 0] = stat.standardize(obs[..., 0])
+        stat.standardize(obs[..., 0], out=x[..., 0])
         vec.action_uniforms(u)
-        if recurrent:
+        if recurrent and agent.agent.hid == 24 and hasattr(agent, "policy_step_hip"):
+            a = torch.empty(N, dtype=torch.int64, device=dev)             # K14: GRU cell + heads + draw in one launch
+            agent.policy_step_hip(x[:, 0].contiguous(), bank.predict(x)[:, 0].contiguous(), hid, u=u[:, 0].contiguous(), h_out=hid, act=a)
+        elif recurrent:
             logits, _, hid = agent.agent.policy_step(x[:, 0], bank.predict(x)[:, 0], hid)
             cdf = torch.cumsum(torch.softmax(logits, dim=-1), dim=-1)
             a = (cdf[:, :-1] <= u[:, 0].unsqueeze(-1)).sum(dim=-1)

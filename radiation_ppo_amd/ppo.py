@@ -11,6 +11,7 @@ Mirrors (paths relative to the reference root):
                          StepLR(100, 0.99)); N envs play the role of the reference's N MPI ranks
                          (gradient = mean over ranks of each rank's mean over its episodes).
 """
+import ctypes as C
 from dataclasses import dataclass
 from typing import Any, Dict, Optional
 
@@ -163,13 +164,49 @@ class FusedPPOGrad:
 class DeviceWelford:
     """StatisticStandardization (RADTEAM_core.py:188-277) for every (env, agent) at once, float64."""
 
-    def __init__(self, shape, device):
+    def __init__(self, shape, device, impl: Optional[str] = None):
+        """impl: "hip" (default on a cuda device) or "torch" (the element-wise composition; the only form for CPU tensors)."""
+        self.impl = impl or ("hip" if torch.device(device).type == "cuda" else "torch")
+        assert self.impl in ("hip", "torch") and (self.impl == "torch" or torch.device(device).type == "cuda")
         self.count = torch.zeros(shape, dtype=torch.float64, device=device)
         self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
         self.sq = torch.zeros(shape, dtype=torch.float64, device=device)
         self.std = torch.ones(shape, dtype=torch.float64, device=device)
 
+    # On the GPU the three operations are one launch each (csrc/rs_welford.hip: the same float64 arithmetic, bit for bit); the
+    # element-wise composition below is what the kernels are tested against and what CPU tensors (host-logic tests) use.
+    @staticmethod
+    def _strided(t: torch.Tensor):
+        """(tensor, element stride) for a [N, A] view whose flattened (n, a) index has one stride (obs[..., 0] of [N, A, 11])."""
+        if t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) > 0 and t.stride(0) == t.shape[1] * t.stride(1):
+            return t, t.stride(1)
+        if t.dim() == 1 and t.dtype == torch.float32 and t.stride(0) > 0:
+            return t, t.stride(0)
+        t = t.float().contiguous()
+        return t, 1
+
+    def _hip(self, reading: Optional[torch.Tensor] = None) -> bool:
+        return self.impl == "hip" and self.count.dim() in (1, 2) and (reading is None or reading.shape == self.count.shape)
+
+    def _na(self):
+        return (self.count.shape[0], self.count.shape[1] if self.count.dim() == 2 else 1)
+
+    @staticmethod
+    def _m8(mask: Optional[torch.Tensor]):
+        if mask is None:
+            return None
+        m = mask.contiguous()
+        return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
     def update(self, reading: torch.Tensor, mask: Optional[torch.Tensor] = None) -> None:
+        if self._hip(reading):
+            r, st = self._strided(reading)
+            m8 = self._m8(mask)
+            n, a = self._na()
+            _lib.check(_lib.load().rs_welford_update(self.count.data_ptr(), self.mean.data_ptr(), self.sq.data_ptr(), self.std.data_ptr(),
+                                                     r.data_ptr(), st, None if m8 is None else m8.data_ptr(), n, a,
+                                                     C.c_void_p(torch.cuda.current_stream(self.count.device).cuda_stream)), "rs_welford_update")
+            return
         x = reading.double()
         count = self.count + 1
         first = count == 1
@@ -185,10 +222,33 @@ class DeviceWelford:
         # in place: a captured collector step (HIP graph) refers to these tensors by address
         self.count.copy_(count); self.mean.copy_(mean_new); self.sq.copy_(sq_new); self.std.copy_(std_new)
 
-    def standardize(self, reading: torch.Tensor) -> torch.Tensor:
-        return ((reading.double() - self.mean) / self.std).float()
+    def standardize(self, reading: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out: an optional float32 destination view of the same shape (e.g. x[..., 0] of a cloned observation)."""
+        if self._hip(reading):
+            r, st = self._strided(reading)
+            if out is None:
+                out = torch.empty(self.count.shape, dtype=torch.float32, device=self.count.device)
+            o, ost = self._strided(out)
+            assert o.data_ptr() == out.data_ptr(), "standardize(out=...) needs a float32 view with one element stride"
+            _lib.check(_lib.load().rs_welford_standardize(self.mean.data_ptr(), self.std.data_ptr(), r.data_ptr(), st, o.data_ptr(), ost,
+                                                          self.count.numel(),
+                                                          C.c_void_p(torch.cuda.current_stream(self.count.device).cuda_stream)),
+                       "rs_welford_standardize")
+            return out
+        z = ((reading.double() - self.mean) / self.std).float()
+        if out is not None:
+            out.copy_(z)
+            return out
+        return z
 
     def reset(self, mask: torch.Tensor) -> None:
+        if self._hip():
+            n, a = self._na()
+            m8 = self._m8(mask)
+            _lib.check(_lib.load().rs_welford_reset(self.count.data_ptr(), self.mean.data_ptr(), self.sq.data_ptr(), self.std.data_ptr(),
+                                                    m8.data_ptr(), n, a, C.c_void_p(torch.cuda.current_stream(self.count.device).cuda_stream)),
+                       "rs_welford_reset")
+            return
         m = mask.view(-1, *([1] * (self.count.dim() - 1))).expand_as(self.count)
         self.count.masked_fill_(m, 0.0); self.mean.masked_fill_(m, 0.0); self.sq.masked_fill_(m, 0.0); self.std.masked_fill_(m, 1.0)
 
@@ -468,7 +528,7 @@ class Collector:
         if not self.standardize:
             return obs
         x = obs.clone()
-        x[..., 0] = self.stat.standardize(obs[..., 0])
+        self.stat.standardize(obs[..., 0], out=x[..., 0])
         return x
 
     def start(self) -> None:

@@ -741,7 +741,7 @@ class RNNCollector:
 
     def _x(self, obs: torch.Tensor) -> torch.Tensor:
         x = obs.clone()
-        x[..., 0] = self.stat.standardize(obs[..., 0])
+        self.stat.standardize(obs[..., 0], out=x[..., 0])
         return x
 
     def _reset_hidden(self, mask: Optional[torch.Tensor]) -> None:

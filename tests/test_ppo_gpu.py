@@ -457,3 +457,35 @@ def test_fused_grad_and_adam_step_match_reference_update_rada2c(golden_dir):
             big = np.abs(d[f"{tag}_grad_{k}"]) > 1e-5 if not term else np.ones_like(want, dtype=bool)
             assert np.allclose(got[big], want[big], rtol=0, atol=3e-6), (tag, k, np.abs(got - want)[big].max())
             assert np.abs(got - want).max() <= 6.1e-4, (tag, k)
+
+
+def test_welford_kernels_equal_the_float64_composition():
+    """rs_welford_update / _reset / _standardize (DeviceWelford on the GPU) against the element-wise float64 composition
+    (impl="torch") on the same device: bitwise, over masked updates, resets and a strided reading column (obs[..., 0] of
+    [N, A, 11]); against the composition on the CPU (another sqrt / division implementation) to the last bits."""
+    from radiation_ppo_amd.ppo import DeviceWelford
+    g = torch.Generator().manual_seed(5)
+    N, A = 301, 3
+    dev, cpu, host = DeviceWelford((N, A), "cuda"), DeviceWelford((N, A), "cuda", impl="torch"), DeviceWelford((N, A), "cpu")
+    for step in range(12):
+        obs = (torch.rand(N, A, 11, generator=g) * (50.0 if step % 3 else 5000.0)).float()
+        mask = (torch.rand(N, generator=g) < 0.6) if step % 2 else None
+        og = obs.cuda()
+        mg = None if mask is None else mask.cuda()
+        dev.update(og[..., 0], mg); cpu.update(og[..., 0], mg); host.update(obs[..., 0], mask)
+        if step in (4, 9):
+            rm = torch.rand(N, generator=g) < 0.3
+            dev.reset(rm.cuda()); cpu.reset(rm.cuda()); host.reset(rm)
+        for name in ("count", "mean", "sq", "std"):
+            a, b, c = getattr(dev, name), getattr(cpu, name), getattr(host, name)
+            assert torch.equal(a, b), (step, name)
+            assert torch.allclose(a.cpu(), c, rtol=1e-14, atol=0.0), (step, name)
+        x = og.clone()
+        z = dev.standardize(og[..., 0], out=x[..., 0])
+        assert torch.equal(x[..., 0], cpu.standardize(og[..., 0])) and torch.equal(x[..., 1:], og[..., 1:]) and z.data_ptr() == x.data_ptr()
+        assert torch.equal(dev.standardize(og[..., 0]), cpu.standardize(og[..., 0]))
+    one, ref = DeviceWelford((N,), "cuda"), DeviceWelford((N,), "cuda", impl="torch")      # the 1-D form (FusedCollector.start)
+    r = (torch.rand(N, generator=g) * 100).cuda()
+    one.update(r); ref.update(r)
+    one.update(r * 2); ref.update(r * 2)
+    assert torch.equal(one.mean, ref.mean) and torch.equal(one.std, ref.std)

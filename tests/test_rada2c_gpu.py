@@ -248,6 +248,8 @@ def test_pfgru_training_kernel_matches_autograd(l1):
     kd = KernelDraws(B.key * 64 + 1, B.X.shape[0])
     loss_k, slab, idx = ag.model_pass_hip(B, sl, kd)
     gk = unpack_train_grads(cell, slab)
+    loss_2, slab_2, idx_2 = ag.model_pass_hip(B, sl, kd)                # the LDS scatter-add is wave-private: bitwise repeatable
+    assert torch.equal(slab, slab_2) and torch.equal(idx, idx_2) and float(loss_k) == float(loss_2)
     cell.train()
     for p in cell.parameters():
         p.grad = None
