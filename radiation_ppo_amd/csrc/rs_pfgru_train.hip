@@ -42,6 +42,10 @@ static_assert(T_STRIDE == RS_PFGRU_TRAIN_WEIGHT_FLOATS, "include/radsearch.h: RS
 constexpr int G_ZR = 0, G_N = G_ZR + 48 * 28, G_H0 = G_N + 48 * 28, G_H2 = G_H0 + 24 * 25, G_O = G_H2 + 50, G_END = G_O + 28;
 static_assert(G_END <= RS_PFGRU_TRAIN_GRAD_FLOATS, "include/radsearch.h: RS_PFGRU_TRAIN_GRAD_FLOATS");
 
+#ifndef RS_PF_AHEAD
+#define RS_PF_AHEAD 2                     // weight rows requested ahead of the row in use (16 SGPRs each)
+#endif
+
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -65,18 +69,22 @@ template <int K, int OUTP, typename F>
 __device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
 #pragma unroll
     for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wq[3][16];
+        float acc[16], wq[RS_PF_AHEAD + 1][16];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wq[0][o] = W[16 * ch + o]; wq[1][o] = W[OUTP + 16 * ch + o]; }
+        for (int o = 0; o < 16; ++o) acc[o] = out[16 * ch + o];
+#pragma unroll
+        for (int a = 0; a < RS_PF_AHEAD; ++a)
+#pragma unroll
+            for (int o = 0; o < 16; ++o) wq[a][o] = W[(a < K ? a : 0) * OUTP + 16 * ch + o];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (k + 2 < K) {
+            if (k + RS_PF_AHEAD < K) {
 #pragma unroll
-                for (int o = 0; o < 16; ++o) wq[(k + 2) % 3][o] = W[(k + 2) * OUTP + 16 * ch + o];
+                for (int o = 0; o < 16; ++o) wq[(k + RS_PF_AHEAD) % (RS_PF_AHEAD + 1)][o] = W[(k + RS_PF_AHEAD) * OUTP + 16 * ch + o];
             }
             const float c = cval(k);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % 3][o], c, acc[o]);
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % (RS_PF_AHEAD + 1)][o], c, acc[o]);
 #pragma unroll
             for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
             __builtin_amdgcn_sched_barrier(0);
@@ -94,22 +102,24 @@ __device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
 template <int K, int OUTP, typename F>
 __device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
     constexpr int CH = OUTP / 16, NB = K * CH;
-    float wq[3][16];
+    float wq[RS_PF_AHEAD + 1][16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) { wq[0][o] = W[o]; wq[1][o] = W[16 + o]; }
+    for (int a = 0; a < RS_PF_AHEAD; ++a)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) wq[a][o] = W[(a < NB ? a : 0) * 16 + o];
     float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        if (b + 2 < NB) {
+        if (b + RS_PF_AHEAD < NB) {
 #pragma unroll
-            for (int o = 0; o < 16; ++o) wq[(b + 2) % 3][o] = W[(b + 2) * 16 + o];
+            for (int o = 0; o < 16; ++o) wq[(b + RS_PF_AHEAD) % (RS_PF_AHEAD + 1)][o] = W[(b + RS_PF_AHEAD) * 16 + o];
         }
         const int k = b / CH, ch = b % CH;
         if (ch == 0) { a0 = 0.0f; a1 = 0.0f; }
 #pragma unroll
         for (int o = 0; o < 16; o += 2) {
-            a0 = fmaf(wq[b % 3][o], cval(16 * ch + o), a0);
-            a1 = fmaf(wq[b % 3][o + 1], cval(16 * ch + o + 1), a1);
+            a0 = fmaf(wq[b % (RS_PF_AHEAD + 1)][o], cval(16 * ch + o), a0);
+            a1 = fmaf(wq[b % (RS_PF_AHEAD + 1)][o + 1], cval(16 * ch + o + 1), a1);
         }
         asm volatile("" : "+v"(a0), "+v"(a1));
         if (ch == CH - 1) out[k] += a0 + a1;
