@@ -377,6 +377,12 @@ int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
 
+/* _get_init_states (RADA2C_core.py:458-461) for the envs with mask[n] != 0 (all when NULL): GRU state h [A][N][24] ~
+ * U(-scale, scale), scale = 1 / sqrt(24), from the counter hash of the env's key base_key [A][N] and its episode counter
+ * episodes_begun [N] (documented RNG deviation: the reference draws from torch's global generator). */
+int rs_gru_h0_reset(float* h, const int64_t* base_key, const int64_t* episodes_begun, const uint8_t* mask, double scale, int32_t num_envs,
+                    int32_t num_agents, rs_stream_t stream);
+
 /* ---- running observation statistics ------------------------------------------------------------
  * StatisticStandardization.update / standardize / reset (NeuralNetworkCores/RADTEAM_core.py:188-277) for num_envs x num_agents
  * independent streams, float64 state count / mean / sq (square_dist_mean) / std, one pass each:

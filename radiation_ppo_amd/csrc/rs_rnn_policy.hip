@@ -166,9 +166,42 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     }
 }
 
+// splitmix64 finaliser == pfgru.py: hash_bits (csrc/rs_pfgru.hip: pf_hash)
+__device__ __forceinline__ uint64_t gh_hash(uint64_t key) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// _get_init_states (RADA2C_core.py:458-461) for the envs that begin an episode: h0 ~ U(-scale, scale) from the counter hash
+// (kind 5 of the env's key, episode counter = episodes_begun[n]); one lane per (agent, env, unit).  The torch composition of the
+// same hash was ~30 int64 element-wise launches per lock-step of the collector.
+__global__ void __launch_bounds__(256) rs_gru_h0_kernel(float* __restrict__ h, const int64_t* __restrict__ base, const int64_t* __restrict__ begun,
+                                                        const uint8_t* __restrict__ mask, float scale, int N, int A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)A * N * GH) return;
+    const int j = (int)(i % GH);
+    const long long slot = i / GH;
+    const int n = (int)(slot % N);
+    if (mask && !mask[n]) return;
+    const uint64_t key = ((uint64_t)base[slot] * 1000003ull) ^ (((uint64_t)begun[n] * 8ull + 5ull) * 0xA24BAED4963EE407ull);
+    const double u = (double)(gh_hash(key * 1048583ull + (uint64_t)j) >> 11) * (1.0 / 9007199254740992.0);
+    h[i] = ((float)u * 2.0f - 1.0f) * scale;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rs_gru_h0_reset(float* h, const int64_t* base_key, const int64_t* episodes_begun, const uint8_t* mask, double scale, int32_t num_envs,
+                    int32_t num_agents, rs_stream_t stream) {
+    if (!h || !base_key || !episodes_begun || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
+    const long long lanes = (long long)num_envs * num_agents * GH;
+    hipLaunchKernelGGL(rs_gru_h0_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h, base_key,
+                       episodes_begun, mask, (float)scale, num_envs, num_agents);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream) {

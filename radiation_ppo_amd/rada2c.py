@@ -749,6 +749,12 @@ class RNNCollector:
         self.bank.reset(mask)
         m = torch.ones(self.N, dtype=torch.bool, device=self.h.device) if mask is None else mask.bool()
         self.episodes_begun.add_(m.long())
+        if self.use_k14:                                                       # the same hash in one launch (rs_gru_h0_reset)
+            m8 = m.view(torch.uint8)
+            _lib.check(_lib.load().rs_gru_h0_reset(self.h.data_ptr(), self.bank._base.data_ptr(), self.episodes_begun.data_ptr(), m8.data_ptr(),
+                                                   1.0 / math.sqrt(self.agents[0].agent.hid), self.N, self.A,
+                                                   C.c_void_p(torch.cuda.current_stream(self.h.device).cuda_stream)), "rs_gru_h0_reset")
+            return
         key = (self.bank._base * 1000003) ^ ((self.episodes_begun.view(1, -1) * 8 + 5) * _s64(0xA24BAED4963EE407))      # [A, N]
         u = hash_uniform(key.unsqueeze(-1) * 1048583 + self._gidx.view(1, 1, -1))
         h0 = self.agents[0].agent.gru_h0(u)

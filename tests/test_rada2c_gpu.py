@@ -352,3 +352,28 @@ def test_policy_step_kernel_matches_torch_composition():
         with torch.no_grad():                                            # an optimiser step bumps the versions: the pack follows
             for p in ag.agent.pi.parameters():
                 p.add_(0.01)
+
+
+def test_gru_h0_reset_kernel_equals_the_hash_composition():
+    """rs_gru_h0_reset (one launch) against the torch composition of the same counter hash in RNNCollector._reset_hidden: bitwise,
+    masked envs only."""
+    env, agents, col = _make(70, 8, 4)
+    col.start()
+    g = torch.Generator().manual_seed(3)
+    for rep in range(3):
+        mask = (torch.rand(70, generator=g) < 0.5).cuda() if rep else None
+        begun = col.episodes_begun.clone()
+        h_before = col.h.clone()
+        pf = (col.bank.h.clone(), col.bank.p.clone(), col.bank.episode.clone(), col.bank.calls.clone())
+        assert col.use_k14
+        col._reset_hidden(mask)
+        got = col.h.clone()
+        # rewind and take the composition
+        col.episodes_begun.copy_(begun); col.h.copy_(h_before)
+        col.bank.h.copy_(pf[0]); col.bank.p.copy_(pf[1]); col.bank.episode.copy_(pf[2]); col.bank.calls.copy_(pf[3])
+        col.use_k14 = False
+        col._reset_hidden(mask)
+        col.use_k14 = True
+        assert torch.equal(got, col.h), rep
+        if mask is not None:
+            assert torch.equal(got[:, ~mask], h_before[:, ~mask]) and not torch.equal(got[:, mask], h_before[:, mask])
