@@ -397,6 +397,14 @@ int rs_welford_reset(double* count, double* mean, double* sq, double* std, const
 int rs_welford_standardize(const double* mean, const double* std, const float* reading, int64_t stride, float* out, int64_t out_stride,
                            int32_t streams, rs_stream_t stream);
 
+/* The logger statistics train() accumulates per epoch and agent id (algos/multiagent/train.py:386-398, :494-501, :519-526), one
+ * lock-step of all envs: acc_oob[a] += sum_n out_of_bounds[n][a]; acc_done[a] += sum_n done[n][a]; over the envs whose episode
+ * ended (over[n] != 0): ep_cnt += 1, ep_len += steps_in_ep[n], ret_sum[a] += r, ret_sq[a] += r^2, ret_max / ret_min (r =
+ * ep_ret[n][a]).  float64 accumulators, fixed summation order. */
+int rs_epoch_stats(const uint8_t* out_of_bounds, const uint8_t* done, const float* ep_ret, const int32_t* steps_in_ep, const uint8_t* over,
+                   double* acc_oob, double* acc_done, double* ep_cnt, double* ep_len, double* ret_sum, double* ret_sq, double* ret_max,
+                   double* ret_min, int32_t num_envs, int32_t num_agents, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

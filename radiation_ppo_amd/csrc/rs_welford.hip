@@ -1,4 +1,5 @@
-// rs_welford.hip -- the running observation statistics of the collectors as three one-pass kernels.
+// rs_welford.hip -- the running observation statistics of the collectors as three one-pass kernels, and their per-epoch logger
+// statistics as one.
 //
 // Replaces the element-wise composition of StatisticStandardization (NeuralNetworkCores/RADTEAM_core.py:188-277; StatBuff in
 // RADA2C_core.py) in radiation_ppo_amd/ppo.py: DeviceWelford -- ~25 float64 element-wise launches per update, ~60 per lock-step
@@ -46,9 +47,73 @@ __global__ void __launch_bounds__(256) rs_welford_standardize_kernel(const doubl
     out[(long long)i * out_stride] = (float)(((double)reading[(long long)i * stride] - mean[i]) / sd[i]);
 }
 
+// The per-epoch logger statistics of the collectors (train.py:386-398, :494-501, :519-526; ppo.py: EpochStats) for one lock-step:
+// out-of-bounds and terminal counts per agent id, and count / length / sum / sum of squares / max / min of the returns of the
+// episodes that ended.  One workgroup, fixed summation order (lane-private sums over n = lane, lane + 256, ..., then a tree).
+constexpr int ES_MAXA = RS_MAX_AGENTS;
+__global__ void __launch_bounds__(256) rs_epoch_stats_kernel(const uint8_t* __restrict__ oob, const uint8_t* __restrict__ done,
+                                                             const float* __restrict__ ep_ret, const int32_t* __restrict__ steps,
+                                                             const uint8_t* __restrict__ over, double* __restrict__ acc_oob,
+                                                             double* __restrict__ acc_done, double* __restrict__ ep_cnt, double* __restrict__ ep_len,
+                                                             double* __restrict__ ret_sum, double* __restrict__ ret_sq, double* __restrict__ ret_max,
+                                                             double* __restrict__ ret_min, int N, int A) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    // value kinds: 0 oob[a], 1 done[a], 2 sum[a], 3 sq[a], 4 max[a], 5 min[a] (a < A), then 6 * A: count, 6 * A + 1: length
+    for (int q = 0; q < 6 * A + 2; ++q) {
+        const int kind = q < 6 * A ? q / A : 6 + (q - 6 * A), a = q < 6 * A ? q % A : 0;
+        double v = kind == 4 ? -INFINITY : (kind == 5 ? INFINITY : 0.0);
+        for (int n = tid; n < N; n += 256) {
+            const bool ov = over[n] != 0;
+            const double r = (double)ep_ret[(size_t)n * A + a];
+            switch (kind) {
+                case 0: v += (double)oob[(size_t)n * A + a]; break;
+                case 1: v += (double)done[(size_t)n * A + a]; break;
+                case 2: if (ov) v += r; break;
+                case 3: if (ov) v += r * r; break;
+                case 4: if (ov) v = fmax(v, r); break;
+                case 5: if (ov) v = fmin(v, r); break;
+                case 6: if (ov) v += 1.0; break;
+                default: if (ov) v += (double)steps[n]; break;
+            }
+        }
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s >= 1; s >>= 1) {
+            if (tid < s) red[tid] = kind == 4 ? fmax(red[tid], red[tid + s]) : (kind == 5 ? fmin(red[tid], red[tid + s]) : red[tid] + red[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double t = red[0];
+            switch (kind) {
+                case 0: acc_oob[a] += t; break;
+                case 1: acc_done[a] += t; break;
+                case 2: ret_sum[a] += t; break;
+                case 3: ret_sq[a] += t; break;
+                case 4: ret_max[a] = fmax(ret_max[a], t); break;
+                case 5: ret_min[a] = fmin(ret_min[a], t); break;
+                case 6: ep_cnt[0] += t; break;
+                default: ep_len[0] += t; break;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rs_epoch_stats(const uint8_t* out_of_bounds, const uint8_t* done, const float* ep_ret, const int32_t* steps_in_ep, const uint8_t* over,
+                   double* acc_oob, double* acc_done, double* ep_cnt, double* ep_len, double* ret_sum, double* ret_sq, double* ret_max,
+                   double* ret_min, int32_t num_envs, int32_t num_agents, rs_stream_t stream) {
+    if (!out_of_bounds || !done || !ep_ret || !steps_in_ep || !over || !acc_oob || !acc_done || !ep_cnt || !ep_len || !ret_sum || !ret_sq ||
+        !ret_max || !ret_min || num_envs < 1 || num_agents < 1 || num_agents > ES_MAXA)
+        return RS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rs_epoch_stats_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out_of_bounds, done, ep_ret, steps_in_ep,
+                       over, acc_oob, acc_done, ep_cnt, ep_len, ret_sum, ret_sq, ret_max, ret_min, num_envs, num_agents);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_welford_update(double* count, double* mean, double* sq, double* std, const float* reading, int64_t stride, const uint8_t* mask,
                       int32_t num_envs, int32_t num_agents, rs_stream_t stream) {

@@ -495,6 +495,23 @@ class EpochStats:
         self.ep_len += (steps_in_ep.double() * over).sum()
         self.ep_cnt += over.double().sum()
 
+    def step_and_episodes(self, out_of_bounds: torch.Tensor, done: torch.Tensor, ep_ret: torch.Tensor, steps_in_ep: torch.Tensor,
+                          over: torch.Tensor) -> None:
+        """step() + episodes() of one lock-step; on the GPU one launch (rs_epoch_stats) instead of ~25 reductions."""
+        ok = (self.oob.is_cuda and out_of_bounds.dtype == torch.uint8 and done.dtype == torch.uint8 and ep_ret.dtype == torch.float32
+              and steps_in_ep.dtype == torch.int32 and over.dtype == torch.bool
+              and all(t.is_contiguous() for t in (out_of_bounds, done, ep_ret, steps_in_ep, over)))
+        if not ok:
+            self.step(out_of_bounds, done)
+            self.episodes(ep_ret, steps_in_ep, over)
+            return
+        N, A = ep_ret.shape
+        _lib.check(_lib.load().rs_epoch_stats(out_of_bounds.data_ptr(), done.data_ptr(), ep_ret.data_ptr(), steps_in_ep.data_ptr(),
+                                              over.view(torch.uint8).data_ptr(), self.oob.data_ptr(), self.done.data_ptr(),
+                                              self.ep_cnt.data_ptr(), self.ep_len.data_ptr(), self.ret_sum.data_ptr(), self.ret_sq.data_ptr(),
+                                              self.ret_max.data_ptr(), self.ret_min.data_ptr(), N, A,
+                                              C.c_void_p(torch.cuda.current_stream(self.oob.device).cuda_stream)), "rs_epoch_stats")
+
     def result(self) -> Dict[str, torch.Tensor]:
         return dict(DoneCount=self.done.clone(), OutOfBound=self.oob.clone(), EpCount=self.ep_cnt.clone(), EpLenSum=self.ep_len.clone(),
                     EpRetSum=self.ret_sum.clone(), EpRetSqSum=self.ret_sq.clone(), EpRetMax=self.ret_max.clone(), EpRetMin=self.ret_min.clone())

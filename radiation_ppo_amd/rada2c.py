@@ -804,7 +804,7 @@ class RNNCollector:
         self.ep_ret += rew
         self.steps_in_ep += 1
         terminal = done.bool().any(dim=1)
-        acc.step(info["out_of_bounds"], done)
+        oob_now = info["out_of_bounds"]
         timeout = self.steps_in_ep == L
         episode_over = terminal | timeout
         cut = torch.ones_like(episode_over) if epoch_ended else episode_over
@@ -822,7 +822,7 @@ class RNNCollector:
                 _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
             self._row_f[2, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
         put(buf.last_val, self._row_f[2])
-        acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
+        acc.step_and_episodes(oob_now, done, self.ep_ret, self.steps_in_ep, episode_over)     # before the reset rewrites the env's rows
         if epoch_ended:
             env.set_epoch_end()
         self.stat.reset(cut)

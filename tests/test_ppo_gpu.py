@@ -489,3 +489,25 @@ def test_welford_kernels_equal_the_float64_composition():
     one.update(r); ref.update(r)
     one.update(r * 2); ref.update(r * 2)
     assert torch.equal(one.mean, ref.mean) and torch.equal(one.std, ref.std)
+
+
+def test_epoch_stats_kernel_equals_the_reductions():
+    """rs_epoch_stats (EpochStats.step_and_episodes: one launch per lock-step) against the step() + episodes() reductions: counts,
+    extrema and episode counters exactly, float64 sums to summation-order rounding; a no-episode step leaves max / min at +-inf."""
+    from radiation_ppo_amd.ppo import EpochStats
+    g = torch.Generator().manual_seed(6)
+    for N, A in ((1000, 1), (333, 4)):
+        k, t = EpochStats(A, "cuda"), EpochStats(A, "cuda")
+        for step in range(6):
+            oob = (torch.rand(N, A, generator=g) < 0.2).to(torch.uint8).cuda()
+            done = (torch.rand(N, A, generator=g) < 0.1).to(torch.uint8).cuda()
+            ret = (torch.randn(N, A, generator=g) * 30).float().cuda()
+            steps = torch.randint(1, 121, (N,), generator=g, dtype=torch.int32).cuda()
+            over = (torch.rand(N, generator=g) < (0.0 if step == 0 else 0.15)).cuda()
+            k.step_and_episodes(oob, done, ret, steps, over)
+            t.step(oob, done); t.episodes(ret, steps, over)
+            a, b = k.result(), t.result()
+            for name in ("DoneCount", "OutOfBound", "EpCount", "EpLenSum", "EpRetMax", "EpRetMin"):
+                assert torch.equal(a[name], b[name]), (N, A, step, name)
+            for name in ("EpRetSum", "EpRetSqSum"):
+                assert torch.allclose(a[name], b[name], rtol=1e-13, atol=1e-9), (N, A, step, name)
