@@ -269,7 +269,7 @@ class CNNCollector:
         self.ep_ret += r_used
         self.steps_in_ep += 1
         terminal = done.bool().any(dim=1)
-        acc.step(info["out_of_bounds"], done)
+        oob_now = info["out_of_bounds"]
         timeout = self.steps_in_ep == L
         episode_over = terminal | timeout
         cut = torch.ones_like(episode_over) if epoch_ended else episode_over
@@ -286,7 +286,7 @@ class CNNCollector:
                 vb = ag._values((critic_b,))
             self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
         put(buf.last_val, self._row_f[2])
-        acc.episodes(self.ep_ret, self.steps_in_ep, episode_over)
+        acc.step_and_episodes(oob_now, done, self.ep_ret, self.steps_in_ep, episode_over)   # one launch (rs_epoch_stats); before the reset
         self.complete_len.copy_(torch.where(episode_over, (ti + 1).expand(N), self.complete_len))
         if epoch_ended:
             env.set_epoch_end()
