@@ -540,18 +540,21 @@ class RNNAgentPPO:
         """model_loss + backward for an episode chunk on K13 (rs_pfgru_train): returns (loss, summed gradient slab, idx [L, E, 40])."""
         a = self.bp_args
         dev = self.device
-        B, sl = B.chunk(sl), slice(None)
-        X = B.X[:, sl].contiguous()
+        # what does not change between the iterations of update_model is prepared once per chunk and kept on the batch
+        cache = B.__dict__.setdefault("_k13", {})
+        ck = (sl.start, sl.stop, a.bp_decay, a.area_scale)
+        if ck not in cache:
+            Bc = B.chunk(sl)
+            X = Bc.X.contiguous()
+            L, E = X.shape[0], X.shape[1]
+            tt = torch.arange(L, device=dev, dtype=torch.float64).unsqueeze(1)
+            bp = torch.exp(a.bp_decay * tt) * Bc.valid.double()
+            bp = (bp / bp.sum(dim=0, keepdim=True)).float().contiguous()           # :1074-1075
+            cache[ck] = (X, (Bc.src / a.area_scale).float().contiguous(), bp, Bc.lens.contiguous(), Bc.w_ep.float().contiguous(),
+                         torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev), torch.empty(L, E, 40, dtype=torch.float32, device=dev),
+                         torch.zeros(L, E, 40, dtype=torch.int32, device=dev))     # idx: steps beyond an episode's end are never written
+        X, tar, bp, lens, w_ep, hs, ps, idx = cache[ck]
         L, E = X.shape[0], X.shape[1]
-        valid, lens = B.valid[:, sl], B.lens[sl].contiguous()
-        tar = (B.src[:, sl] / a.area_scale).float().contiguous()
-        tt = torch.arange(L, device=dev, dtype=torch.float64).unsqueeze(1)
-        bp = torch.exp(a.bp_decay * tt) * valid.double()
-        bp = (bp / bp.sum(dim=0, keepdim=True)).float().contiguous()               # :1074-1075
-        w_ep = B.w_ep[sl].float().contiguous()
-        hs = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
-        ps = torch.empty(L, E, 40, dtype=torch.float32, device=dev)
-        idx = torch.zeros(L, E, 40, dtype=torch.int32, device=dev)              # steps beyond an episode's end are never written
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
         w = pack_train_weights(self.agent.model)
