@@ -492,7 +492,7 @@ class RNNAgentPPO:
         p = torch.empty(1, E, 40, dtype=torch.float32, device=dev)
         base = draws.k.contiguous().view(1, E)
         episode = torch.ones(E, dtype=torch.int64, device=dev)
-        calls = torch.zeros(E, dtype=torch.int64, device=dev)
+        calls = torch.arange(L, dtype=torch.int64, device=dev).view(L, 1).expand(L, E).contiguous()   # the step counter of every launch
         wts = pack_weights([self.agent.model])
         loc = torch.zeros(L, E, 2, dtype=torch.float32, device=dev)
         # episodes sorted by descending length: the ones still running at step t are a prefix, the launch covers only those
@@ -500,14 +500,13 @@ class RNNAgentPPO:
         if lens_host is not None and all(a >= b for a, b in zip(lens_host, lens_host[1:])):
             asc = lens_host[::-1]
             alive = [E - bisect.bisect_right(asc, t) for t in range(L)]
-        _lib.check(lib.rs_pfgru_reset(h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(), None, E, 1, st),
+        _lib.check(lib.rs_pfgru_reset(h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls[0].data_ptr(), None, E, 1, st),
                    "rs_pfgru_reset")
         Xc = X.contiguous()
         for t in range(L):
             _lib.check(lib.rs_pfgru_step(wts.data_ptr(), Xc[t].data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(),
-                                         calls.data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), alive[t], 1, st),
+                                         calls[t].data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), alive[t], 1, st),
                        "rs_pfgru_step")
-            calls.add_(1)
         return loc
 
     def model_loss(self, B: EpisodeBatch, sl: slice, draws) -> torch.Tensor:
