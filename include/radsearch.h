@@ -377,6 +377,18 @@ int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
 
+/* The heads of the RAD-A2C actor-critic, update_rada2c's per-sample loss (algos/multiagent/ppo.py:1191-1234: PPO-clip surrogate on
+ * the policy head, vf_coef x squared error on the value head; the entropy term carries no gradient) and their back-propagation,
+ * for `samples` (step, episode) rows behind the GRU:
+ *   hs [S][24], act [S], adv [S], ret [S], logp_old [S], sample_weight [S] (w_ep / episode length; 0 on padded steps)
+ *   -> dhs [S][24] = dL/dh (what rs_gru_backward takes), dfac [S][80] = d pre-tanh of the policy head [32] | of the value head [32]
+ *      | d logits [8] | d value | zeros, tfac [S][64] = tanh outputs of the two heads: the caller forms the weight gradients
+ *      (dW1 = dfac[:, :32]^T hs, dW2 = dfac[:, 64:72]^T tfac[:, :32], ...; biases = column sums of dfac);
+ *      stats [ceil(S / 64)][8]: per-wave weighted sums of kl, entropy, clip fraction, value loss, surrogate, weight. */
+int rs_a2c_heads_loss(const float* weights, const float* hs, const int64_t* act, const float* adv, const float* ret, const float* logp_old,
+                      const float* sample_weight, float* dhs, float* dfac, float* tfac, float* stats, int64_t samples, double clip_ratio,
+                      double vf_coef, rs_stream_t stream);
+
 /* _get_init_states (RADA2C_core.py:458-461) for the envs with mask[n] != 0 (all when NULL): GRU state h [A][N][24] ~
  * U(-scale, scale), scale = 1 / sqrt(24), from the counter hash of the env's key base_key [A][N] and its episode counter
  * episodes_begun [N] (documented RNG deviation: the reference draws from torch's global generator). */

@@ -166,6 +166,164 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     }
 }
 
+// out[k] += sum_o W[k][o] c(o) on a k-major [K][OUTP] block (the transposed product: a dot product along each row), as K13's mvt
+template <int K, int OUTP, typename F>
+__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
+    constexpr int CH = OUTP / 16, NB = K * CH;
+    float wq[3][16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) { wq[0][o] = W[o]; wq[1][o] = W[16 + o]; }
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 2 < NB) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) wq[(b + 2) % 3][o] = W[(b + 2) * 16 + o];
+        }
+        const int k = b / CH, ch = b % CH;
+        if (ch == 0) { a0 = 0.0f; a1 = 0.0f; }
+#pragma unroll
+        for (int o = 0; o < 16; o += 2) {
+            a0 = fmaf(wq[b % 3][o], cval(16 * ch + o), a0);
+            a1 = fmaf(wq[b % 3][o + 1], cval(16 * ch + o + 1), a1);
+        }
+        asm volatile("" : "+v"(a0), "+v"(a1));
+        if (ch == CH - 1) out[k] += a0 + a1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// K15: heads, per-sample PPO-clip / value loss and their back-propagation for every (step, episode) sample of an episode chunk:
+// update_rada2c's loss (algos/multiagent/ppo.py:1191-1234) behind the GRU.  One sample per lane.  Writes dL/dh (the input of K12's
+// backward), the per-sample factors of the head weight gradients (the caller reduces the outer products with batched GEMMs) and
+// per-wave partial sums of the statistics.  The loss derivative is K7's (csrc/rs_ppo_grad2.hpp), pinned to the reference there.
+struct HeadArgs {
+    const float* w;        // packed policy weights (K14 layout; the head blocks are used)
+    const float* hs;       // [S][24]
+    const int64_t* act;    // [S]
+    const float* adv;      // [S]
+    const float* ret;      // [S]
+    const float* lpo;      // [S] log-probability at collection time
+    const float* wt;       // [S] sample weight (0 on padded steps)
+    float* dhs;            // [S][24]
+    float* dfac;           // [S][80]: d pre-tanh (policy head) [32] | d pre-tanh (value head) [32] | d logits [8] | d value | 0 x 7
+    float* tfac;           // [S][64]: tanh (policy head) [32] | tanh (value head) [32]
+    float* stats;          // [waves][8]: kl, entropy, clip fraction, value loss, surrogate, weight sum, 0, 0 (weighted sums)
+    long long S;
+    float clip, vf_coef;
+};
+
+__global__ void __launch_bounds__(64) rs_a2c_heads_kernel(HeadArgs a_) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = i < a_.S;
+    const long long ic = live ? i : a_.S - 1;
+    const cmem_t W = as_cmem(a_.w);
+    float h[GH];
+#pragma unroll
+    for (int u = 0; u < GH; u += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(a_.hs + ic * GH + u);
+        h[u] = v.x; h[u + 1] = v.y; h[u + 2] = v.z; h[u + 3] = v.w;
+    }
+    const float wi = live ? a_.wt[ic] : 0.0f;
+    const int a = (int)a_.act[ic];
+    const float adv = a_.adv[ic], ret = a_.ret[ic], lpo = a_.lpo[ic];
+    float tp[HD], tv[HD];
+#pragma unroll
+    for (int o = 0; o < HD; ++o) { tp[o] = W[P_B1 + o]; tv[o] = W[P_VB1 + o]; }
+    mv<GH, HD>(W + P_W1, [&](int k) -> float { return h[k]; }, tp);
+    mv<GH, HD>(W + P_V1, [&](int k) -> float { return h[k]; }, tv);
+#pragma unroll
+    for (int o = 0; o < HD; ++o) { tp[o] = tanh_(tp[o]); tv[o] = tanh_(tv[o]); }
+    float lg[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) lg[o] = W[P_B2 + o];
+    mv<HD, 16>(W + P_W2, [&](int k) -> float { return tp[k]; }, lg);
+    float v0 = W[P_V2 + HD], v1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < HD; k += 2) {
+        v0 = fmaf(W[P_V2 + k], tv[k], v0);
+        v1 = fmaf(W[P_V2 + k + 1], tv[k + 1], v1);
+    }
+    const float val = v0 + v1;
+    // ---- per-sample loss terms and derivative (K7's formulas)
+    float mx = lg[0];
+#pragma unroll
+    for (int j = 1; j < NA; ++j) mx = fmaxf(mx, lg[j]);
+    float se = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) se += expf(lg[j] - mx);
+    const float lse = logf(se);
+    float pj[NA], ent = 0.0f, logp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const float lp = (lg[j] - mx) - lse;
+        pj[j] = expf(lp);
+        ent -= pj[j] * lp;
+        logp = (a == j) ? lp : logp;
+    }
+    const float ratio = expf(logp - lpo);
+    const float lo = 1.0f - a_.clip, hi = 1.0f + a_.clip;
+    const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, lo), hi) * adv;
+    const bool inside = ratio >= lo && ratio <= hi;
+    const float g_lp = -wi * (((inside || s1 < s2) ? adv : 0.0f) * ratio);
+    float dl[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dl[j] = j < NA ? g_lp * (((a == j) ? 1.0f : 0.0f) - pj[j < NA ? j : 0]) : 0.0f;
+    const float diff = val - ret;
+    const float dval = 2.0f * a_.vf_coef * wi * diff;
+    // ---- back through the heads
+    float dp[HD], dv[HD];
+#pragma unroll
+    for (int k = 0; k < HD; ++k) dp[k] = 0.0f;
+    // the backward products read the same rows as the forward ones: a laundered pointer keeps GVN from holding (and spilling) them
+    auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
+    mvt<HD, 16>(wptr() + P_W2, [&](int o) -> float { return dl[o]; }, dp);
+#pragma unroll
+    for (int k = 0; k < HD; ++k) {
+        dp[k] = dp[k] * (1.0f - tp[k] * tp[k]);
+        dv[k] = wptr()[P_V2 + k] * dval * (1.0f - tv[k] * tv[k]);
+    }
+    float dh[GH];
+#pragma unroll
+    for (int j = 0; j < GH; ++j) dh[j] = 0.0f;
+    mvt<GH, HD>(wptr() + P_W1, [&](int k) -> float { return dp[k]; }, dh);
+    mvt<GH, HD>(wptr() + P_V1, [&](int k) -> float { return dv[k]; }, dh);
+    if (live) {
+        float* o = a_.dhs + i * GH;
+#pragma unroll
+        for (int u = 0; u < GH; u += 4) *reinterpret_cast<float4*>(o + u) = make_float4(dh[u], dh[u + 1], dh[u + 2], dh[u + 3]);
+        float* d = a_.dfac + i * 80;
+#pragma unroll
+        for (int u = 0; u < HD; u += 4) {
+            *reinterpret_cast<float4*>(d + u) = make_float4(dp[u], dp[u + 1], dp[u + 2], dp[u + 3]);
+            *reinterpret_cast<float4*>(d + HD + u) = make_float4(dv[u], dv[u + 1], dv[u + 2], dv[u + 3]);
+        }
+        *reinterpret_cast<float4*>(d + 64) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        *reinterpret_cast<float4*>(d + 68) = make_float4(dl[4], dl[5], dl[6], dl[7]);
+        *reinterpret_cast<float4*>(d + 72) = make_float4(dval, 0.0f, 0.0f, 0.0f);
+        *reinterpret_cast<float4*>(d + 76) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float* t = a_.tfac + i * 64;
+#pragma unroll
+        for (int u = 0; u < HD; u += 4) {
+            *reinterpret_cast<float4*>(t + u) = make_float4(tp[u], tp[u + 1], tp[u + 2], tp[u + 3]);
+            *reinterpret_cast<float4*>(t + HD + u) = make_float4(tv[u], tv[u + 1], tv[u + 2], tv[u + 3]);
+        }
+    }
+    // ---- statistics: weighted sums over the wave
+    float st[6] = {wi * (lpo - logp), wi * ent, wi * ((ratio > hi || ratio < lo) ? 1.0f : 0.0f), wi * diff * diff, wi * fminf(s1, s2), wi};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) st[q] += __shfl_xor(st[q], sft);
+    }
+    if (threadIdx.x == 0) {
+        float* so = a_.stats + (long long)blockIdx.x * 8;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) so[q] = st[q];
+        so[6] = 0.0f; so[7] = 0.0f;
+    }
+}
+
 // splitmix64 finaliser == pfgru.py: hash_bits (csrc/rs_pfgru.hip: pf_hash)
 __device__ __forceinline__ uint64_t gh_hash(uint64_t key) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
@@ -193,6 +351,16 @@ __global__ void __launch_bounds__(256) rs_gru_h0_kernel(float* __restrict__ h, c
 }  // namespace
 
 extern "C" {
+
+int rs_a2c_heads_loss(const float* weights, const float* hs, const int64_t* act, const float* adv, const float* ret, const float* logp_old,
+                      const float* sample_weight, float* dhs, float* dfac, float* tfac, float* stats, int64_t samples, double clip_ratio,
+                      double vf_coef, rs_stream_t stream) {
+    if (!weights || !hs || !act || !adv || !ret || !logp_old || !sample_weight || !dhs || !dfac || !tfac || !stats || samples < 1)
+        return RS_ERR_INVALID_ARG;
+    HeadArgs a{weights, hs, act, adv, ret, logp_old, sample_weight, dhs, dfac, tfac, stats, (long long)samples, (float)clip_ratio, (float)vf_coef};
+    hipLaunchKernelGGL(rs_a2c_heads_kernel, dim3((unsigned)((samples + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_gru_h0_reset(float* h, const int64_t* base_key, const int64_t* episodes_begun, const uint8_t* mask, double scale, int32_t num_envs,
                     int32_t num_agents, rs_stream_t stream) {

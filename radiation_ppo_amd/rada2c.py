@@ -137,6 +137,54 @@ class RNNModelActorCritic(nn.Module):
         return (u.float() * 2.0 - 1.0) * std
 
 
+def _two_step(d: torch.Tensor, x: torch.Tensor, R: int = 1024) -> torch.Tensor:
+    """d^T x for tall d [S, O], x [S, I]: batched partial products over R-row slabs, then a sum (see _LinearRows)."""
+    m = (d.shape[0] // R) * R
+    out = d[m:].t() @ x[m:]
+    if m:
+        out = out + torch.bmm(d[:m].view(m // R, R, -1).transpose(1, 2), x[:m].view(m // R, R, -1)).sum(dim=0)
+    return out
+
+
+class HeadsLoss(torch.autograd.Function):
+    """update_rada2c's loss behind the GRU on K15 (rs_a2c_heads_loss): heads, per-sample PPO-clip / value loss and their
+    back-propagation in one launch; the head weight gradients are reduced from the per-sample factors with batched GEMMs.
+    forward -> (-(surrogate - vf * value loss) as a scalar that back-propagates, statistics [kl, entropy, clip fraction, value loss,
+    surrogate, weight sum] float64, no gradient).  The gradients are formed in forward (the loss is only ever differentiated)."""
+
+    @staticmethod
+    def forward(ctx, hs, w1, b1, w2, b2, v1, vb1, v2, vb2, packed, act, adv, ret, logp_old, wt, clip, vf):
+        S = hs.shape[0]
+        dev = hs.device
+        hs = hs.contiguous()
+        dhs = torch.empty(S, 24, dtype=torch.float32, device=dev)
+        dfac = torch.empty(S, 80, dtype=torch.float32, device=dev)
+        tfac = torch.empty(S, 64, dtype=torch.float32, device=dev)
+        stats = torch.empty((S + 63) // 64, 8, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().rs_a2c_heads_loss(packed.data_ptr(), hs.data_ptr(), act.data_ptr(), adv.data_ptr(), ret.data_ptr(),
+                                                 logp_old.data_ptr(), wt.data_ptr(), dhs.data_ptr(), dfac.data_ptr(), tfac.data_ptr(),
+                                                 stats.data_ptr(), S, float(clip), float(vf),
+                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_a2c_heads_loss")
+        st = stats.double().sum(dim=0)[:6]
+        g1 = _two_step(dfac[:, :64], hs)                                  # [64, 24]: Woms[0] | Valms[0]
+        g2 = _two_step(dfac[:, 64:72], tfac[:, :32])                      # [8, 32]
+        g3 = _two_step(dfac[:, 72:73], tfac[:, 32:])                      # [1, 32]
+        m = (S // 1024) * 1024
+        gb = dfac[m:].sum(dim=0)
+        if m:
+            gb = gb + dfac[:m].view(m // 1024, 1024, 80).sum(dim=1).sum(dim=0)
+        ctx.save_for_backward(dhs, g1, g2, g3, gb)
+        loss = (-(st[4] - vf * st[3])).float()
+        ctx.mark_non_differentiable(st)
+        return loss, st
+
+    @staticmethod
+    def backward(ctx, g, _):
+        dhs, g1, g2, g3, gb = ctx.saved_tensors
+        return (g * dhs, g * g1[:32], g * gb[:32], g * g2, g * gb[64:72], g * g1[32:], g * gb[32:64], g * g3, g * gb[72:73],
+                None, None, None, None, None, None, None, None)
+
+
 class GRUSequence(torch.autograd.Function):
     """torch.nn.GRU(13, 24, 1) over an episode-major batch with the recurrence in K12 (csrc/rs_gru.hip): x [L, E, 13], h0 [E, 24]
     -> h_t [L, E, 24].  Forward: one GEMM for the input projection of all (t, episode), then the time loop in one launch (one
@@ -624,6 +672,19 @@ class RNNAgentPPO:
         else:
             with torch.backends.cudnn.flags(enabled=False):    # (the library path; on the GPU MIOpen's RNN backward is slower than native)
                 hs, _ = g(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
+        if X.is_cuda and ac.hid == 24 and getattr(self, "use_k15", True):
+            # K15: heads + per-sample loss + their back-propagation in one launch
+            v = ac.pi.logits_net.v_net
+            flat = lambda t: t.reshape(L * E).contiguous()
+            loss_g, st = HeadsLoss.apply(hs.reshape(L * E, -1), v.Woms[0].weight, v.Woms[0].bias, v.Woms[2].weight, v.Woms[2].bias,
+                                         v.Valms[0].weight, v.Valms[0].bias, v.Valms[2].weight, v.Valms[2].bias, self.policy_weights(),
+                                         flat(B.act[:, sl]), flat(B.adv[:, sl]), flat(B.ret[:, sl]), flat(B.logp[:, sl]), flat(w),
+                                         self.clip_ratio, 0.01)
+            with torch.no_grad():
+                d2 = (w.unsqueeze(-1) * (self.env_height * loc - B.src[:, sl]) ** 2).sum().double() / 2.0
+                loss_val = -(st[4] - 0.01 * st[3] + self.alpha * st[1])             # the logged loss includes the (detached) entropy term
+                stats = torch.stack([st[0], st[1], st[2], st[3], loss_val, d2, st[5]])
+            return loss_g, stats
         logits, val = ac.heads(hs.reshape(L * E, -1))
         logp_all = torch.log_softmax(logits.view(L, E, -1), dim=-1)               # Categorical(logits=...) (:443-446)
         val = val.view(L, E)

@@ -377,3 +377,37 @@ def test_gru_h0_reset_kernel_equals_the_hash_composition():
         assert torch.equal(got, col.h), rep
         if mask is not None:
             assert torch.equal(got[:, ~mask], h_before[:, ~mask]) and not torch.equal(got[:, mask], h_before[:, mask])
+
+
+def test_policy_update_with_k15_equals_the_torch_heads():
+    """One update_rada2c pass with the heads + loss + their back-propagation on K15 (rs_a2c_heads_loss) against the same pass with
+    the torch heads and autograd: statistics and every pi gradient (heads AND, through dL/dh, the GRU)."""
+    from radiation_ppo_amd.rada2c import HashDraws, RNNAgentPPO, pack_episodes
+    g = torch.Generator().manual_seed(19)
+    T, N = 60, 150
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    adv, ret = torch.randn(T, N, generator=g).cuda(), torch.randn(T, N, generator=g).cuda()
+    logp = (float(np.log(1 / 8)) + 0.25 * torch.randn(T, N, generator=g)).cuda()          # wide enough to hit both clip sides
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.08).to(torch.uint8)
+    cut[-1] = 1
+    B = pack_episodes(obs, act, adv, ret, logp, src, cut.cuda(), n_total=N, seed=3, sort_by_length=True)
+    out = []
+    for k15 in (True, False):
+        torch.manual_seed(22)
+        ag = RNNAgentPPO(id=0, seed=1, alpha=0.1)
+        with torch.no_grad():
+            for p in ag.agent.pi.parameters():
+                p.mul_(1.5)
+        ag.use_k15 = k15
+        ag.agent.train()
+        ag.pi_optimizer.zero_grad(set_to_none=True)
+        loss, st = ag.a2c_losses(B, slice(0, B.lens.shape[0]), HashDraws(B.key * 64 + 17))
+        loss.backward()
+        out.append((st.clone(), {k: p.grad.clone() for k, p in ag.agent.pi.named_parameters()}))
+    assert float(out[1][0][2]) > 0.01                                     # some samples are clipped
+    assert torch.allclose(out[0][0], out[1][0], rtol=2e-5, atol=1e-7), (out[0][0], out[1][0])
+    for k in out[0][1]:
+        a, b = out[0][1][k], out[1][1][k]
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()) + 1e-9), (k, float((a - b).abs().max()), float(b.abs().max()))
