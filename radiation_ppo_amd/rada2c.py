@@ -649,16 +649,41 @@ class RNNAgentPPO:
         cell.eval()
         return last
 
-    def a2c_losses(self, B: EpisodeBatch, sl: slice, draws):
+    def loc_prefetch(self, B: EpisodeBatch, it: int):
+        """The no-grad PFGRU passes of policy iteration `it` (K11, every chunk) enqueued on a side stream: they depend on the batch and
+        on the PFGRU's weights only -- not on the policy being updated -- so iteration it + 1's passes (VALU bound, the whole chip)
+        run under iteration it's GRU recurrence (66 waves, latency bound), its head / loss kernels and the Adam step.
+        Returns ([loc per chunk], event)."""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        if it == 0:
+            self._side.wait_stream(main)                                     # the batch and update_model's weights are final
+        out = []
+        E = B.lens.shape[0]
+        with torch.cuda.stream(self._side), torch.no_grad():
+            for lo in range(0, E, self.episode_chunk):
+                Bc = B.chunk(slice(lo, min(lo + self.episode_chunk, E)))
+                loc = self._pfgru_pass_hip(Bc.X, HashDraws(Bc.key * 64 + 17 + it), Bc.lens_host)
+                loc.record_stream(main)
+                out.append(loc)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return out, ev
+
+    def a2c_losses(self, B: EpisodeBatch, sl: slice, draws, loc: Optional[torch.Tensor] = None):
         """grad_step (:550-566) + the per-episode loss of update_rada2c (ppo.py:1191-1234) for an episode chunk.
-        Returns (loss to back-propagate, stats [kl, ent, clipfrac, val_loss, loss, sum w (h loc - src)^2, sum w])."""
+        Returns (loss to back-propagate, stats [kl, ent, clipfrac, val_loss, loss, sum w (h loc - src)^2, sum w]).
+        loc: the chunk's PFGRU location predictions when they were computed ahead (loc_prefetch)."""
         ac = self.agent
         B, sl = B.chunk(sl), slice(None)
         X, valid = B.X[:, sl], B.valid[:, sl]
         w = B.w[:, sl]
         L, E = X.shape[0], X.shape[1]
         with torch.no_grad():
-            if isinstance(draws, HashDraws) and X.is_cuda:
+            if loc is not None:
+                pass
+            elif isinstance(draws, HashDraws) and X.is_cuda:
                 loc = self._pfgru_pass_hip(X, draws, B.lens_host)          # K11 with carried particle sets: one launch per step
             else:
                 loc, _ = self._pfgru_pass(X[..., :3], draws, False)
@@ -704,15 +729,15 @@ class RNNAgentPPO:
         stats = torch.stack([kl, ent, cf, val_loss.detach(), loss.detach(), d2, w.sum()]).double()
         return loss, stats
 
-    def update_rada2c(self, B: EpisodeBatch, it: int = 0, draws_for=None):
-        """One call of update_rada2c: returns (stats list, terminated)."""
+    def update_rada2c(self, B: EpisodeBatch, it: int = 0, draws_for=None, locs=None):
+        """One call of update_rada2c: returns (stats list, terminated).  locs: loc_prefetch(B, it)[0]."""
         E = B.lens.shape[0]
         self.pi_optimizer.zero_grad(set_to_none=True)
         stats = torch.zeros(7, dtype=torch.float64, device=self.device)
-        for lo in range(0, E, self.episode_chunk):
+        for ci, lo in enumerate(range(0, E, self.episode_chunk)):
             sl = slice(lo, min(lo + self.episode_chunk, E))
             d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 17 + it)
-            loss, st = self.a2c_losses(B, sl, d)
+            loss, st = self.a2c_losses(B, sl, d, loc=None if locs is None else locs[ci])
             loss.backward()
             stats += st
         if _world() > 1:
@@ -730,9 +755,18 @@ class RNNAgentPPO:
         model_loss = self.update_model(B)
         self.pi_optimizer.zero_grad(set_to_none=True)
         kk, term, s = 0, False, None
+        ahead = self.device.type == "cuda" and getattr(self, "use_prefetch", True)
+        nxt = self.loc_prefetch(B, 0) if ahead else None
         while not term and kk < self.train_pi_iters:
-            s, term = self.update_rada2c(B, kk)
+            cur = nxt
+            if ahead:
+                # iteration kk + 1's PFGRU passes go to the side stream before iteration kk's own work is enqueued
+                nxt = self.loc_prefetch(B, kk + 1) if kk + 1 < self.train_pi_iters else None
+                torch.cuda.current_stream(self.device).wait_event(cur[1])
+            s, term = self.update_rada2c(B, kk, locs=cur[0] if ahead else None)
             kk += 1
+        if ahead:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)   # a pass enqueued for an iteration the KL stop cancelled
         self.pi_scheduler.step(); self.pfgru_scheduler.step()
         self.agent.eval()
         self.epochs_done += 1

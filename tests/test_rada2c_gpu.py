@@ -411,3 +411,32 @@ def test_policy_update_with_k15_equals_the_torch_heads():
     for k in out[0][1]:
         a, b = out[0][1][k], out[1][1][k]
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()) + 1e-9), (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_update_agent_with_prefetched_pfgru_passes_equals_the_serial_schedule():
+    """update_agent with the PFGRU passes of the next policy iteration enqueued on a side stream (loc_prefetch) against the same
+    update with everything on one stream: same draws, same arithmetic -> identical parameters and statistics."""
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, pack_episodes
+    g = torch.Generator().manual_seed(23)
+    T, N = 48, 80
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    adv, ret = torch.randn(T, N, generator=g).cuda(), torch.randn(T, N, generator=g).cuda()
+    logp = (float(np.log(1 / 8)) + 0.05 * torch.randn(T, N, generator=g)).cuda()
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.1).to(torch.uint8)
+    cut[-1] = 1
+    B = pack_episodes(obs, act, adv, ret, logp, src, cut.cuda(), n_total=N, seed=3, sort_by_length=True)
+    res = []
+    for pre in (True, False):
+        torch.manual_seed(31)
+        ag = RNNAgentPPO(id=0, seed=1, train_pi_iters=4, train_pfgru_iters=1, episode_chunk=128)
+        ag.use_prefetch = pre
+        r = ag.update_agent(B)
+        torch.cuda.synchronize()
+        res.append((r, torch.cat([p.detach().reshape(-1) for p in ag.agent.parameters()])))
+    a, b = res
+    assert a[0].stop_iteration == b[0].stop_iteration
+    for k in ("loss_policy", "loss_critic", "kl_divergence", "Entropy", "ClipFrac", "LocLoss"):
+        assert getattr(a[0], k) == getattr(b[0], k), (k, getattr(a[0], k), getattr(b[0], k))
+    assert torch.equal(a[1], b[1])
