@@ -389,6 +389,13 @@ int rs_a2c_heads_loss(const float* weights, const float* hs, const int64_t* act,
                       const float* sample_weight, float* dhs, float* dfac, float* tfac, float* stats, int64_t samples, double clip_ratio,
                       double vf_coef, rs_stream_t stream);
 
+/* The PPO-clip actor loss of the RAD-TEAM update behind the logits (AgentPPO.compute_loss_pi, algos/multiagent/ppo.py:966-1003) and its
+ * derivative, one pass: logits [S][8], act [S], adv [S], logp_old [S], sample_weight [S] ->
+ *   dlogits [S][8] = d (-sum_s w_s min(ratio_s adv_s, clip(ratio_s) adv_s)) / d logits,
+ *   stats [ceil(S / 64)][4]: per-wave weighted sums of kl (logp_old - logp), entropy, clip fraction and the loss itself. */
+int rs_actor_loss(const float* logits, const int64_t* act, const float* adv, const float* logp_old, const float* sample_weight,
+                  float* dlogits, float* stats, int64_t samples, double clip_ratio, rs_stream_t stream);
+
 /* _get_init_states (RADA2C_core.py:458-461) for the envs with mask[n] != 0 (all when NULL): GRU state h [A][N][24] ~
  * U(-scale, scale), scale = 1 / sqrt(24), from the counter hash of the env's key base_key [A][N] and its episode counter
  * episodes_begun [N] (documented RNG deviation: the reference draws from torch's global generator). */

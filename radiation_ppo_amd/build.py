@@ -14,7 +14,7 @@ LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librs_hip.so")
 
-SOURCES = ["rs_env.hip", "rs_ppo.hip", "rs_maps.hip", "rs_cnn.hip", "rs_pfgru.hip", "rs_gru.hip", "rs_pfgru_train.hip", "rs_rnn_policy.hip", "rs_welford.hip"]
+SOURCES = ["rs_env.hip", "rs_ppo.hip", "rs_maps.hip", "rs_cnn.hip", "rs_pfgru.hip", "rs_gru.hip", "rs_pfgru_train.hip", "rs_rnn_policy.hip", "rs_welford.hip", "rs_cnn_loss.hip"]
 # -ffp-contract=off: float64 env arithmetic must round like the reference's Python floats (no FMA fusing)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
           "-Wno-unused-function"]

@@ -12,6 +12,7 @@ Heat-map channel 0 (location prediction) is fed by every owner's PFGRU cell (rad
 f1) exactly as the reference's CNN harness uses it: forward-only, untrained weights, every prediction made from the episode's
 h0 (algos/test_cnn/train.py:686-693, ppo.py:737-738); `use_predictor=False` leaves the channel empty.
 """
+import ctypes as C
 import os
 from typing import Any, Dict, Optional
 
@@ -23,6 +24,32 @@ from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps
 from .pfgru import PredictorBank
 from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
+
+
+class ActorLoss(torch.autograd.Function):
+    """compute_loss_pi behind the logits (ppo.py:966-1003) on rs_actor_loss: returns (loss, [kl, entropy, clip fraction, loss] float64);
+    the derivative wrt the logits is formed in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, act, adv, logp_old, w, clip):
+        S = logits.shape[0]
+        # the contiguous copies stay referenced until the launch is enqueued (a column of the [T, N, A] buffers flattens to a strided view)
+        logits, act, adv, logp_old, w = (t.contiguous() for t in (logits, act, adv, logp_old, w))
+        assert act.dtype == torch.int64 and all(t.dtype == torch.float32 for t in (logits, adv, logp_old, w))
+        dl = torch.empty_like(logits)
+        stats = torch.empty((S + 63) // 64, 4, dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.load().rs_actor_loss(logits.data_ptr(), act.data_ptr(), adv.data_ptr(), logp_old.data_ptr(), w.data_ptr(),
+                                             dl.data_ptr(), stats.data_ptr(), S, float(clip),
+                                             C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)), "rs_actor_loss")
+        st = stats.double().sum(dim=0)
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(st)
+        return st[3].float(), st
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (dl,) = ctx.saved_tensors
+        return g * dl, None, None, None, None, None
 
 
 class CNNAgentPPO:
@@ -96,6 +123,12 @@ class CNNAgentPPO:
             stats = torch.zeros(4, dtype=torch.float64, device=self.device)
             for lo in range(0, M, self.chunk):
                 hi = min(lo + self.chunk, M)
+                if self.device.type == "cuda" and getattr(self, "use_loss_kernel", True):
+                    # the loss, its statistics and its derivative behind the logits in one launch (rs_actor_loss)
+                    loss, st = ActorLoss.apply(self._logits(actor_in(lo, hi)), act[lo:hi], adv[lo:hi], logp_old[lo:hi], w[lo:hi], self.clip_ratio)
+                    loss.backward()
+                    stats += st
+                    continue
                 logp_all = torch.log_softmax(self._logits(actor_in(lo, hi)), dim=-1)
                 logp = logp_all.gather(-1, act[lo:hi].unsqueeze(-1)).squeeze(-1)
                 ratio = torch.exp(logp - logp_old[lo:hi])

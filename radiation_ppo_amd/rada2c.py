@@ -218,7 +218,8 @@ class GRUSequence(torch.autograd.Function):
         dgi = torch.empty(L, E, 3 * H, dtype=torch.float32, device=x.device)
         dgh = torch.empty_like(dgi)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(lib.rs_gru_backward(dhs.contiguous().data_ptr(), hs.data_ptr(), gates.data_ptr(), h0.data_ptr(), whh.data_ptr(),
+        dhs = dhs.contiguous()                                                     # stays referenced until the launch is enqueued
+        _lib.check(lib.rs_gru_backward(dhs.data_ptr(), hs.data_ptr(), gates.data_ptr(), h0.data_ptr(), whh.data_ptr(),
                                        dgi.data_ptr(), dgh.data_ptr(), L, E, st), "rs_gru_backward")
         h_prev = torch.cat((h0.unsqueeze(0), hs[:-1]), dim=0)
         gw_ih = torch.bmm(dgi.transpose(1, 2), x).sum(dim=0)               # per-step partial products, then the sum over time

@@ -29,6 +29,8 @@ if mode == "cnn":
                              actor_learning_rate=3e-3) for i in range(A)}
     for ag in agents.values():
         ag.sync_params()
+        if os.environ.get("RS_TORCH_LOSS_TAIL"):                      # A/B switch: the torch composition of the actor loss
+            ag.use_loss_kernel = False
     col = CNNCollector(env, agents, T, L, True)
     col.collect()
     res = col.update()

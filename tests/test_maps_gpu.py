@@ -357,3 +357,33 @@ def test_cnn_collector_graph_replay_equals_eager_steps():
     for ep in range(2):
         for k in e[ep]:
             assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
+
+
+def test_actor_loss_kernel_equals_the_torch_composition():
+    """rs_actor_loss (ppo_cnn.ActorLoss: compute_loss_pi behind the logits, forward + derivative in one launch) against the torch
+    composition it replaces: loss, kl / entropy / clip-fraction sums, d loss / d logits; both clip sides occur."""
+    import numpy as np
+    from radiation_ppo_amd.ppo_cnn import ActorLoss
+    g = torch.Generator().manual_seed(8)
+    S = 70001
+    logits = (torch.randn(S, 8, generator=g) * 1.5).cuda().requires_grad_(True)
+    act = torch.randint(0, 8, (S,), generator=g).cuda()
+    adv = torch.randn(S, generator=g).cuda()
+    logp_old = (float(np.log(1 / 8)) + 0.5 * torch.randn(S, generator=g)).cuda()
+    w = (torch.rand(S, generator=g) / S).cuda()
+    clip = 0.2
+    loss_k, st = ActorLoss.apply(logits, act, adv, logp_old, w, clip)
+    loss_k.backward()
+    gk = logits.grad.clone()
+    logits.grad = None
+    lp_all = torch.log_softmax(logits, dim=-1)
+    lp = lp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+    ratio = torch.exp(lp - logp_old)
+    loss_t = -(w * torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv)).sum()
+    loss_t.backward()
+    ent = -(lp_all.exp() * lp_all).sum(-1)
+    cf = ((ratio > 1 + clip) | (ratio < 1 - clip)).float()
+    want = torch.stack([(w * (logp_old - lp)).sum(), (w * ent).sum(), (w * cf).sum(), loss_t.detach()]).double()
+    assert 0.1 < float(want[2]) < 0.9
+    assert torch.allclose(st, want, rtol=2e-5, atol=1e-8), (st, want)
+    assert torch.allclose(gk, logits.grad, rtol=1e-4, atol=1e-6 * float(logits.grad.abs().max())), float((gk - logits.grad).abs().max())
