@@ -379,6 +379,7 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
     for _ in range(warmup):
         col.collect(); col.update()
     torch.cuda.synchronize()
+    _lib.EVENTS = {}
     tc = tu = 0.0
     stops = []
     t0 = time.perf_counter()
@@ -388,6 +389,7 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
         tc += b - a; tu += c - b
         stops.append(res[0].stop_iteration)
     dt = time.perf_counter() - t0
+    ev, _lib.EVENTS = _lib.EVENTS, None
     out = {"workload": "single-agent RAD-A2C (GRU(13->24) actor-critic + PFGRU predictor, 40 particles), U{1..5} random rectangles, "
                        "1024 envs, 480 steps/epoch; step = 1 PPO iteration (rollout + 15 PFGRU iterations (K13) + <=40 policy iterations "
                        "through K11 / K12)",
@@ -395,6 +397,19 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
            "policy_iterations": stops, "pfgru_iterations": ag[0].train_pfgru_iters, "env_error_flags": env.error_flags(),
            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    ds = _ms(ev.get("rs_pfgru_train", []))
+    if ds:
+        # K13: 12 180 multiply-adds per particle-step (forward 2 619, the same recomputed in the backward walk, hid_obs forward + backward
+        # 1 248, transposed products 2 328, weight-gradient outer products 3 366), 40 particles per episode-step
+        ms = sum(ds) / len(ds)
+        fl = 2.0 * 12180 * ag[0].k13_particle_steps
+        tf = fl / (ms * 1e-3) / 1e12
+        out["roofline_pfgru_train"] = {"bound": "mfma", "kernel": "rs_pfgru_train_kernel (K13)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                                       "launches_timed": len(ds), "particle_steps_per_launch": ag[0].k13_particle_steps,
+                                       "flops_per_launch": fl,
+                                       "note": "f32 vector/matrix peak (157.3 TFLOP/s); the products run as scalar-weight FMAs on the VALU "
+                                               "(measured f32 VALU peak 124 TFLOP/s), the weight-gradient reductions on the matrix cores"}
     del col, env, ag
     torch.cuda.empty_cache()
     return out

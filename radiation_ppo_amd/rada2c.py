@@ -606,11 +606,13 @@ class RNNAgentPPO:
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
         w = pack_train_weights(self.agent.model)
-        _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
-                                              d._pf.data_ptr(), d._eps.data_ptr(), d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
-                                              idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
-                                              float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
-                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
+        self.k13_particle_steps = int(sum(B.chunk(sl).lens_host)) * 40           # for the bench's roofline entry
+        with _lib.timed("rs_pfgru_train"):
+            _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
+                                                  d._pf.data_ptr(), d._eps.data_ptr(), d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
+                                                  idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
+                                                  float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
         return loss.double().sum(), slab.sum(dim=0), idx
 
     def update_model(self, B: EpisodeBatch, draws_for=None) -> float:
