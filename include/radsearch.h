@@ -424,6 +424,15 @@ int rs_epoch_stats(const uint8_t* out_of_bounds, const uint8_t* done, const floa
                    double* acc_oob, double* acc_done, double* ep_cnt, double* ep_len, double* ret_sum, double* ret_sq, double* ret_max,
                    double* ret_min, int32_t num_envs, int32_t num_agents, rs_stream_t stream);
 
+/* PPOBuffer.store (algos/multiagent/ppo.py:296-389) for one lock-step of every (env, agent): row *t (a device-side counter) of the
+ * time-major rollout buffers receives act [A][N], logp / value / bootstrap value (logp_val_boot [A][3][N]; the bootstrap value only
+ * where boot[n] != 0, else 0), the observation x [N][A][11], the source location (src_x, src_y [N] int32 -> float), the reward
+ * rew [N][A] and the cut flag cut [N]. */
+int rs_store_rows(const int64_t* t, const int64_t* act, const float* logp_val_boot, const float* x, const int32_t* src_x, const int32_t* src_y,
+                  const float* rew, const uint8_t* cut, const uint8_t* boot, int64_t* buf_act, float* buf_logp, float* buf_val,
+                  float* buf_last_val, float* buf_obs, float* buf_source, float* buf_rew, uint8_t* buf_cut, int32_t num_envs,
+                  int32_t num_agents, int32_t steps_per_epoch, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,9 +100,64 @@ __global__ void __launch_bounds__(256) rs_epoch_stats_kernel(const uint8_t* __re
     }
 }
 
+// One lock-step's rows of the rollout buffer (PPOBuffer.store, algos/multiagent/ppo.py:296-389, as the RAD-A2C collector fills it):
+// action, log-probability, value, observation, source location, reward, cut flag and bootstrap value of every (env, agent) go to
+// row *t of the time-major buffers in one launch (the torch collector did ~19: staging copies, index_copy per column, conversions).
+struct StoreArgs {
+    const int64_t* t;        // [1] device-side step counter
+    const int64_t* act;      // [A][N]
+    const float* f;          // [A][3][N]: logp, value, bootstrap value
+    const float* x;          // [N][A][11]
+    const int32_t* src_x;    // [N]
+    const int32_t* src_y;    // [N]
+    const float* rew;        // [N][A]
+    const uint8_t* cut;      // [N]
+    const uint8_t* boot;     // [N]
+    int64_t* b_act;          // [T][N][A]
+    float* b_logp; float* b_val; float* b_last; float* b_obs; float* b_src; float* b_rew;
+    uint8_t* b_cut;
+    int N, A, T;
+};
+
+__global__ void __launch_bounds__(256) rs_store_rows_kernel(StoreArgs a_) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a_.N, A = a_.A;
+    if (i >= N * A) return;
+    const long long t = a_.t[0];
+    if (t < 0 || t >= a_.T) return;
+    const int n = i / A, a = i - n * A;
+    const size_t row = ((size_t)t * N + n) * A + a;
+    a_.b_act[row] = a_.act[(size_t)a * N + n];
+    a_.b_logp[row] = a_.f[((size_t)a * 3 + 0) * N + n];
+    a_.b_val[row] = a_.f[((size_t)a * 3 + 1) * N + n];
+    a_.b_last[row] = a_.boot[n] ? a_.f[((size_t)a * 3 + 2) * N + n] : 0.0f;
+    a_.b_rew[row] = a_.rew[i];
+    a_.b_cut[row] = a_.cut[n] ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < RS_OBS_DIM; ++k) a_.b_obs[row * RS_OBS_DIM + k] = a_.x[(size_t)i * RS_OBS_DIM + k];
+    if (a == 0) {
+        a_.b_src[((size_t)t * N + n) * 2] = (float)a_.src_x[n];
+        a_.b_src[((size_t)t * N + n) * 2 + 1] = (float)a_.src_y[n];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rs_store_rows(const int64_t* t, const int64_t* act, const float* logp_val_boot, const float* x, const int32_t* src_x, const int32_t* src_y,
+                  const float* rew, const uint8_t* cut, const uint8_t* boot, int64_t* buf_act, float* buf_logp, float* buf_val,
+                  float* buf_last_val, float* buf_obs, float* buf_source, float* buf_rew, uint8_t* buf_cut, int32_t num_envs,
+                  int32_t num_agents, int32_t steps_per_epoch, rs_stream_t stream) {
+    if (!t || !act || !logp_val_boot || !x || !src_x || !src_y || !rew || !cut || !boot || !buf_act || !buf_logp || !buf_val || !buf_last_val ||
+        !buf_obs || !buf_source || !buf_rew || !buf_cut || num_envs < 1 || num_agents < 1 || steps_per_epoch < 1)
+        return RS_ERR_INVALID_ARG;
+    StoreArgs a{t, act, logp_val_boot, x, src_x, src_y, rew, cut, boot, buf_act, buf_logp, buf_val, buf_last_val, buf_obs, buf_source, buf_rew,
+                buf_cut, num_envs, num_agents, steps_per_epoch};
+    const int M = num_envs * num_agents;
+    hipLaunchKernelGGL(rs_store_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_epoch_stats(const uint8_t* out_of_bounds, const uint8_t* done, const float* ep_ret, const int32_t* steps_in_ep, const uint8_t* over,
                    double* acc_oob, double* acc_done, double* ep_cnt, double* ep_len, double* ret_sum, double* ret_sq, double* ret_max,

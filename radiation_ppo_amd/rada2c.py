@@ -880,10 +880,7 @@ class RNNCollector:
                 act = self._k_act[a]
                 ag.policy_step_hip(x[:, a].contiguous(), loc[:, a].contiguous(), self.h[a], u=self._u[:, a].contiguous(), h_out=self.h[a],
                                    value=self._k_f[a, 1], act=act, logp=self._k_f[a, 0])
-                self._row_act[:, a] = act
-                self._row_f[0, :, a] = self._k_f[a, 0]
-                self._row_f[1, :, a] = self._k_f[a, 1]
-                self._act8[:, a] = act.to(torch.int8)
+                self._act8[:, a] = act.to(torch.int8)                         # the buffer rows are written by rs_store_rows below
                 continue
             logits, v, h1 = ag.agent.policy_step(x[:, a], loc[:, a], self.h[a])
             self.h[a] = h1
@@ -894,13 +891,16 @@ class RNNCollector:
             self._row_f[0, :, a] = logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
             self._row_f[1, :, a] = v
             self._act8[:, a] = act.to(torch.int8)
-        put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
-        put(buf.obs, x)
-        self._src[:, 0] = env.state("src_x")[0].float()
-        self._src[:, 1] = env.state("src_y")[0].float()
-        put(buf.source_tar, self._src)
+        fast = self.use_k14                                                   # one store kernel per lock-step instead of ~19 launches
+        if not fast:
+            put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
+            put(buf.obs, x)
+            self._src[:, 0] = env.state("src_x")[0].float()
+            self._src[:, 1] = env.state("src_y")[0].float()
+            put(buf.source_tar, self._src)
         next_obs, rew, team, done, info = env.step(self._act8)
-        put(buf.rew, rew)
+        if not fast:
+            put(buf.rew, rew)
         self.ep_ret += rew
         self.steps_in_ep += 1
         terminal = done.bool().any(dim=1)
@@ -908,7 +908,8 @@ class RNNCollector:
         timeout = self.steps_in_ep == L
         episode_over = terminal | timeout
         cut = torch.ones_like(episode_over) if epoch_ended else episode_over
-        put(buf.cut, cut.unsqueeze(1).to(torch.uint8).expand(N, A).contiguous())
+        if not fast:
+            put(buf.cut, cut.unsqueeze(1).to(torch.uint8).expand(N, A).contiguous())
         self.stat.update(next_obs[..., 0])
         self.obs.copy_(next_obs)
         boot = cut if epoch_ended else timeout                                # train.py:462-487: one more ac.step for the value
@@ -916,12 +917,20 @@ class RNNCollector:
         locb = self.bank.predict(xb, mask=boot)
         for a, ag in self.agents.items():
             if self.use_k14:
-                vb = self._k_f[a, 2]
-                ag.policy_step_hip(xb[:, a].contiguous(), locb[:, a].contiguous(), self.h[a], value=vb)
-            else:
-                _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
+                ag.policy_step_hip(xb[:, a].contiguous(), locb[:, a].contiguous(), self.h[a], value=self._k_f[a, 2])
+                continue
+            _, vb, _ = ag.agent.policy_step(xb[:, a], locb[:, a], self.h[a])
             self._row_f[2, :, a] = torch.where(boot, vb, torch.zeros_like(vb))
-        put(buf.last_val, self._row_f[2])
+        if fast:
+            # PPOBuffer.store for the whole lock-step; before the reset moves the sources of the envs that start a new episode
+            _lib.check(_lib.load().rs_store_rows(ti.data_ptr(), self._k_act.data_ptr(), self._k_f.data_ptr(), x.data_ptr(),
+                                                 env.state("src_x").data_ptr(), env.state("src_y").data_ptr(), rew.data_ptr(),
+                                                 cut.view(torch.uint8).data_ptr(), boot.view(torch.uint8).data_ptr(), buf.act.data_ptr(),
+                                                 buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(), buf.obs.data_ptr(),
+                                                 buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T,
+                                                 C.c_void_p(torch.cuda.current_stream(self.h.device).cuda_stream)), "rs_store_rows")
+        else:
+            put(buf.last_val, self._row_f[2])
         acc.step_and_episodes(oob_now, done, self.ep_ret, self.steps_in_ep, episode_over)     # before the reset rewrites the env's rows
         if epoch_ended:
             env.set_epoch_end()
