@@ -257,9 +257,12 @@ def test_pfgru_training_kernel_matches_autograd(l1):
     loss_t.backward()
     lk, lt = float(loss_k), float(loss_t.detach())
     assert abs(lk - lt) <= 2e-5 * abs(lt), (lk, lt)
+    gmax = max(float(p.grad.abs().max()) for p in cell.parameters())
     for name, p in cell.named_parameters():
         a, b = gk[name], p.grad
-        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()) + 1e-10), (name, float((a - b).abs().max()), float(b.abs().max()))
+        # fc_obs.bias shifts every particle's logit alike and cancels in the log-softmax: its gradient is exactly 0 in exact arithmetic,
+        # rounding noise (~1e-10) on both sides -- hence the floor relative to the largest gradient of the cell
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max()) + 1e-6 * gmax), (name, float((a - b).abs().max()), float(b.abs().max()), gmax)
     # the indices themselves: the torch cell resampling from the same uniforms takes the same particles (valid steps)
     cell.zero_grad(set_to_none=True)
     with torch.no_grad():
