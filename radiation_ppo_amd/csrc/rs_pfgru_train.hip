@@ -36,7 +36,7 @@ constexpr int T_H0 = T_O + 32;             // hid_obs[0] k-major [24][32] (colum
 constexpr int T_H0B = T_H0 + 24 * 32;      // [32]
 constexpr int T_H2 = T_H0B + 32;           // hid_obs[2]: w [2][24], b [2], pad to 64
 constexpr int T_STRIDE = T_H2 + 64;        // 14.7 KB: the whole set stays resident in the 16 KB scalar data cache.  A first version kept
-                                           // transposed copies for the backward products (30 KB): every s_load then missed and a step took 3.5x longer
+                                           // transposed copies for the backward products (30 KB): every s_load then missed and a pass took twice as long
 static_assert(T_STRIDE == RS_PFGRU_TRAIN_WEIGHT_FLOATS, "include/radsearch.h: RS_PFGRU_TRAIN_WEIGHT_FLOATS");
 // gradient slab (floats): dW_zr [48][28] (column 27 = bias) | dW_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28]
 constexpr int G_ZR = 0, G_N = G_ZR + 48 * 28, G_H0 = G_N + 48 * 28, G_H2 = G_H0 + 24 * 25, G_O = G_H2 + 50, G_END = G_O + 28;
