@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         const float s = wave_sum(act ? awo[k] : 0.0f);
         if (lane == 0) g[G_O + k] = s;
     }
+    if (lane < RS_PFGRU_TRAIN_GRAD_FLOATS - G_END) g[G_END + lane] = 0.0f;        // the slab's padding
     if (lane == 0) {
         const float pred = l2w * l2s + l1w * 10.0f * l1s * inv_nel;
         const float part = (l2w * l2ps + l1w * 10.0f * l1ps) * inv_nel;
