@@ -402,11 +402,12 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
         # K13: 12 180 multiply-adds per particle-step (forward 2 619, the same recomputed in the backward walk, hid_obs forward + backward
         # 1 248, transposed products 2 328, weight-gradient outer products 3 366), 40 particles per episode-step
         ms = sum(ds) / len(ds)
-        fl = 2.0 * 12180 * ag[0].k13_particle_steps
+        per_launch = ag[0].k13_particle_steps[-len(ds):]                 # one count per launch, in launch order (as the event pairs)
+        fl = 2.0 * 12180 * sum(per_launch) / len(per_launch)              # mean FLOP per launch; achieved = total FLOP / total time
         tf = fl / (ms * 1e-3) / 1e12
         out["roofline_pfgru_train"] = {"bound": "mfma", "kernel": "rs_pfgru_train_kernel (K13)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-                                       "launches_timed": len(ds), "particle_steps_per_launch": ag[0].k13_particle_steps,
+                                       "launches_timed": len(ds), "particle_steps_per_launch": sum(per_launch) / len(per_launch),
                                        "flops_per_launch": fl,
                                        "note": "f32 vector/matrix peak (157.3 TFLOP/s); the products run as scalar-weight FMAs on the VALU "
                                                "(measured f32 VALU peak 124 TFLOP/s), the weight-gradient reductions on the matrix cores"}

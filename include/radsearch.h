@@ -319,6 +319,12 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
 int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
                   const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
                   int32_t num_agents, rs_stream_t stream);
+/* The same step with the draws supplied instead of hashed: eps [A][N][40][24] = the reparameterisation noise, idx [A][N][40] = the
+ * resampling indices (what FloatTensor.normal_ / torch.multinomial returned in a recorded run of the reference, :1485-1530).  The
+ * arithmetic is the product kernel's (one template, two instantiations); used to hold it to tests/golden/pfgru.npz directly. */
+int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, float* p, const float* eps, const int32_t* idx,
+                           const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
+                           rs_stream_t stream);
 /* reset_hidden (RADTEAM_core.py:2030-2033, PFGRUCell.init_hidden :1643-1652) for the envs with mask[n] != 0 (all when null):
  * h0 ~ U[0,1) from the draw hash, p0 = log(1/40).  episode[] / calls[] must already count the new episode. */
 int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
@@ -338,8 +344,10 @@ int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* 
  * d (w_ep[e] * total_e) / d parameters by back-propagation through time, resampling indices held constant as in autograd.
  *   weights [RS_PFGRU_TRAIN_WEIGHT_FLOATS]  packed parameters (layout: csrc/rs_pfgru_train.hip; packer: rada2c.py)
  *   obs [L][E][11] (columns 0..2 used), target [L][E][2], bp [L][E], lens [E] (1..L; steps beyond are never touched), w_ep [E]
- *   h0 / eps / u  the draws of rs_pfgru_draws
- *   hs [L][E][40][24], ps [L][E][40]  scratch (the resampled particle sets), idx [L][E][40] the resampling indices taken
+ *   h0 / eps / u  the draws of rs_pfgru_draws; u may be NULL: idx[] is then INPUT -- the resampling indices to take (the ones
+ *                 torch.multinomial returned in a recorded run of the reference, tests/golden/rada2c_core.npz)
+ *   hs [L][E][40][24], ps [L][E][40]  scratch (the resampled particle sets), idx [L][E][40] the resampling indices taken (output
+ *                 when u is given)
  *   loss [E] = w_ep[e] * total_e;  grads [E][RS_PFGRU_TRAIN_GRAD_FLOATS] = the episode's gradient slab:
  *   d[fc_z | fc_r] [48][28] (column 27 = bias) | d fc_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28];
  *   the caller sums the slabs over the episodes. */

@@ -102,6 +102,8 @@ struct PfArgs {
     const int64_t* calls;     // [N]
     const uint8_t* mask;      // [N] or null: envs whose carried state is updated
     float* pred;              // [N][A][2]
+    const float* eps_in;      // [A][N][P][H] recorded reparameterisation noise   } REC instantiation only: the draws the reference
+    const int32_t* idx_in;    // [A][N][P]    recorded resampling indices         } made (tests/golden/pfgru.npz, rada2c_core.npz)
     int N, A, carry;
     float alpha, floor_;      // soft-resampling alpha and (1 - alpha) / P, rounded to float32 as torch does for scalars
 };
@@ -109,6 +111,7 @@ struct PfArgs {
 constexpr int PF_ROW = PF_H + 1;                                   // odd row stride: conflict-free row writes and column reads
 constexpr int PF_LDS_WAVE = PF_P * PF_ROW * 4 + PF_P * 8 + 64 * 4; // h tile, cdf (f64), p1 / mean
 
+template <bool REC>
 __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,11 +143,14 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
         for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
     }
     // keys (pfgru.py: PredictorBank._key): kind 1 = reparameterisation noise, 2 = resampling uniforms
-    const uint64_t kb = (uint64_t)a_.base[slot] * 1000003ull;
-    const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n]) * 8ull;
-    const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
-    const uint64_t k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
-    const uint64_t pk = k_eps * 1048583ull + (uint64_t)pl * 4096ull;
+    uint64_t k_res = 0, pk = 0;
+    if constexpr (!REC) {
+        const uint64_t kb = (uint64_t)a_.base[slot] * 1000003ull;
+        const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n]) * 8ull;
+        const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
+        k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
+        pk = k_eps * 1048583ull + (uint64_t)pl * 4096ull;
+    }
 
     // ---- gates: z | r = sigmoid(W_zr [h0, x] + b)
     float g[48];
@@ -157,12 +163,17 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     float h1[PF_H];
 #pragma unroll
     for (int u = 0; u < PF_H; ++u) {
-        const uint64_t hx = pf_hash(pk + (uint64_t)u);
-        const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
-        const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
-        // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
-        // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
-        const float eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+        float eps;
+        if constexpr (REC) {
+            eps = a_.eps_in[(slot * PF_P + pl) * PF_H + u];
+        } else {
+            const uint64_t hx = pf_hash(pk + (uint64_t)u);
+            const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
+            const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
+            // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
+            // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
+            eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+        }
         const float var = m[24 + u];
         const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
         const float y = m[u] + eps * sp;
@@ -193,10 +204,14 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
         vec[lane] = p1;
     }
     __builtin_amdgcn_wave_barrier();
-    const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)pl * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
     int idx = 0;
-    for (int q = 0; q < PF_P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;  // searchsorted(..., right=True)
-    idx = min(idx, PF_P - 1);
+    if constexpr (REC) {
+        idx = min(max(a_.idx_in[slot * PF_P + pl], 0), PF_P - 1);
+    } else {
+        const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)pl * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
+        for (int q = 0; q < PF_P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;  // searchsorted(..., right=True)
+        idx = min(idx, PF_P - 1);
+    }
 #pragma unroll
     for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
     float pn = expf(vec[idx]);
@@ -320,10 +335,22 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
                   int32_t num_agents, rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || num_envs < 1 || num_agents < 1)
         return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, num_envs, num_agents, carry_hidden ? 1 : 0, (float)alpha,
-             (float)((1.0 - alpha) / (double)PF_P)};
+    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0,
+             (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const long long waves = (long long)num_envs * num_agents;
-    hipLaunchKernelGGL(rs_pfgru_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
+    hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
+                       static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, float* p, const float* eps, const int32_t* idx,
+                           const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
+                           rs_stream_t stream) {
+    if (!weights || !obs || !h || !p || !eps || !idx || !pred || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
+    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0,
+             (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
+    const long long waves = (long long)num_envs * num_agents;
+    hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
                        static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

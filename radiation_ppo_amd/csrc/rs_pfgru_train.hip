@@ -168,7 +168,7 @@ struct TrArgs {
     const float* w_ep;        // [E]        weight of the episode's loss
     const float* h0;          // [E][P][H]  initial particles
     const float* eps;         // [L][E][P][H]
-    const double* u;          // [L][E][P]  resampling uniforms
+    const double* u;          // [L][E][P]  resampling uniforms; NULL: idx[] holds the indices to take (recorded draws)
     float* hs;                // [L][E][P][H] scratch: resampled particles after every step
     float* ps;                // [L][E][P]    scratch: their log weights
     int32_t* idx;             // [L][E][P]    resampling indices (output; constants of the backward pass)
@@ -279,10 +279,14 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = h1[u];
             vec[lane] = p1;
             __builtin_amdgcn_wave_barrier();
-            const double ru = a_.u[te * P + pl];
             int idx = 0;
-            for (int q = 0; q < P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;   // searchsorted(..., right=True)
-            idx = min(idx, P - 1);
+            if (a_.u) {
+                const double ru = a_.u[te * P + pl];
+                for (int q = 0; q < P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;   // searchsorted(..., right=True)
+                idx = min(idx, P - 1);
+            } else {
+                idx = min(max(a_.idx[te * P + pl], 0), P - 1);          // what torch.multinomial returned in the reference's run
+            }
 #pragma unroll
             for (int u = 0; u < H; ++u) h0[u] = tile[idx * ROW + u];
             float pn = expf(vec[idx]);
@@ -547,7 +551,7 @@ int rs_pfgru_train(const float* weights, const float* obs, const float* target, 
                    const float* h0, const float* eps, const double* u, float* hs, float* ps, int32_t* idx, float* loss, float* grads,
                    int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
                    rs_stream_t stream) {
-    if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !u || !hs || !ps || !idx || !loss || !grads || steps < 1 ||
+    if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !hs || !ps || !idx || !loss || !grads || steps < 1 ||
         episodes < 1)
         return RS_ERR_INVALID_ARG;
     TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, idx, loss, grads, steps, episodes, (float)alpha,

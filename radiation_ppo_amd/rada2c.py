@@ -295,6 +295,16 @@ class RecordedDraws:
         return dict(resample_idx=self._idx[t])
 
 
+class RecordedKernelDraws(RecordedDraws):
+    """RecordedDraws in the buffers the kernels read (K11: rs_pfgru_step_recorded, K13: rs_pfgru_train with u = NULL): the
+    reference's own h0 / noise / resampling indices go straight into the HIP kernels (tests/test_rows_f_golden_gpu.py)."""
+
+    def __init__(self, pf_h0, gru_h0, eps, idx):
+        super().__init__(pf_h0.contiguous(), gru_h0, eps.contiguous(), idx)
+        self._idx32 = idx.to(torch.int32).contiguous()
+        self._u = None
+
+
 # ------------------------------------------------------------------------------------------------ episode-major batch
 @dataclass
 class EpisodeBatch:
@@ -558,6 +568,24 @@ class RNNAgentPPO:
                        "rs_pfgru_step")
         return loc
 
+    def _pfgru_pass_hip_recorded(self, X: torch.Tensor, draws: "RecordedKernelDraws") -> torch.Tensor:
+        """_pfgru_pass_hip with the draws supplied (K11's recorded-draw instantiation): X [L, E, 11] -> loc [L, E, 2]."""
+        from .pfgru import pack_weights
+        lib = _lib.load()
+        L, E = X.shape[0], X.shape[1]
+        dev = X.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        h = draws.pf_h0().clone().view(1, E, 40, 24)
+        p = torch.full((1, E, 40), math.log(1.0 / 40), dtype=torch.float32, device=dev)
+        wts = pack_weights([self.agent.model])
+        loc = torch.zeros(L, E, 2, dtype=torch.float32, device=dev)
+        Xc = X.contiguous()
+        for t in range(L):
+            _lib.check(lib.rs_pfgru_step_recorded(wts.data_ptr(), Xc[t].data_ptr(), h.data_ptr(), p.data_ptr(), draws._eps[t].data_ptr(),
+                                                  draws._idx32[t].data_ptr(), None, 1, float(self.agent.model.resamp_alpha),
+                                                  loc[t].data_ptr(), E, 1, st), "rs_pfgru_step_recorded")
+        return loc
+
     def model_loss(self, B: EpisodeBatch, sl: slice, draws) -> torch.Tensor:
         """Sum over the chunk's episodes of w_ep x total_loss (ppo.py:1062-1128)."""
         a = self.bp_args
@@ -606,10 +634,14 @@ class RNNAgentPPO:
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
         w = pack_train_weights(self.agent.model)
-        self.k13_particle_steps = int(sum(B.chunk(sl).lens_host)) * 40           # for the bench's roofline entry
+        # for the bench's roofline entry: one count per launch, in launch order (as _lib.EVENTS["rs_pfgru_train"])
+        self.k13_particle_steps = getattr(self, "k13_particle_steps", [])
+        self.k13_particle_steps.append(int(sum(B.chunk(sl).lens_host)) * 40)
+        if d._u is None:                                                           # recorded draws: idx is the kernel's INPUT
+            idx.copy_(d._idx32)
         with _lib.timed("rs_pfgru_train"):
             _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
-                                                  d._pf.data_ptr(), d._eps.data_ptr(), d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
+                                                  d._pf.data_ptr(), d._eps.data_ptr(), None if d._u is None else d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
                                                   idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
                                                   float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
@@ -632,7 +664,7 @@ class RNNAgentPPO:
                     d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0])
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it)
-                if isinstance(d, KernelDraws) and getattr(self, "use_k13", True):
+                if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
                     # K13: the episode loop, the loss and its back-propagation through time in one launch
                     loss, g, _ = self.model_pass_hip(B, sl, d)
                     by_name = unpack_train_grads(cell, g)
@@ -686,6 +718,8 @@ class RNNAgentPPO:
         with torch.no_grad():
             if loc is not None:
                 pass
+            elif isinstance(draws, RecordedKernelDraws) and X.is_cuda:
+                loc = self._pfgru_pass_hip_recorded(X, draws)
             elif isinstance(draws, HashDraws) and X.is_cuda:
                 loc = self._pfgru_pass_hip(X, draws, B.lens_host)          # K11 with carried particle sets: one launch per step
             else:
@@ -956,6 +990,8 @@ class RNNCollector:
         if self.use_k14:
             for ag in self.agents.values():
                 ag.policy_weights()                                           # re-packed in place after an update
+        if self.bank.impl == "hip":
+            self.bank._packed()                # the captured K11 launch reads this buffer: update_model changed the PFGRU since
         if self.use_graph and self._graph is None and T > 1:
             side = torch.cuda.Stream(device=self.env.device)                  # library warm-up (GEMM handles) outside the capture
             side.wait_stream(torch.cuda.current_stream(self.env.device))

@@ -140,7 +140,9 @@ def test_gru_sequence_kernels_match_torch_gru():
 
 
 def test_rnn_collector_graph_replay_equals_eager_steps():
-    """The captured lock-step replayed T - 1 times writes what the eager loop writes (two epochs; same kernels, same draws)."""
+    """The captured lock-step replayed T - 1 times writes what the eager loop writes -- also AFTER the agent changed: an update
+    (update_model moves the PFGRU, update_rada2c the policy) runs between the two epochs, so a replay that kept reading weight
+    buffers packed before the update (K11's per-owner pack, K14's policy pack) would diverge from the eager loop."""
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
     N, T, L = 48, 26, 8
@@ -148,16 +150,27 @@ def test_rnn_collector_graph_replay_equals_eager_steps():
     def run(use_graph):
         torch.manual_seed(4)
         env = RadSearchVec(N, number_agents=1, obstruction_count=2, enforce_grid_boundaries=True, seed=SEED, env_id_base=16)
-        agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, seed=3)}
+        agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, seed=3, train_pi_iters=2, train_pfgru_iters=2)}
         col = RNNCollector(env, agents, T, L, use_graph=use_graph)
         out = []
-        for _ in range(2):
+        for ep in range(2):
             st = col.collect()
             out.append({**{k: getattr(col.buf, k).clone() for k in ("obs", "act", "rew", "val", "logp", "last_val", "cut", "adv", "ret", "source_tar")},
                         **{"stat_" + k: v.clone() for k, v in st.items()}})
+            if ep == 0:
+                before = torch.cat([p.detach().reshape(-1).clone() for p in agents[0].agent.parameters()])
+                col.update()
+                with torch.no_grad():                                   # and a visible move of both modules on top of the Adam steps
+                    for p in agents[0].agent.model.parameters():
+                        p.mul_(1.25)
+                    for p in agents[0].agent.pi.parameters():
+                        p.mul_(1.5)
+                after = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()])
+                assert not torch.equal(before, after)
         assert (col._graph is not None) == use_graph
         return out
     g, e = run(True), run(False)
+    assert not torch.equal(e[0]["val"], e[1]["val"])
     for ep in range(2):
         for k in e[ep]:
             assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
@@ -292,8 +305,10 @@ def _pre_resample(cell, X3, h0, p0, eps):
 
 def test_update_model_on_k13_equals_autograd_path():
     """update_model end to end (draws, K13 passes, clip, Adam) against the same call on the torch-autograd path: the PFGRU's
-    parameters after two iterations."""
-    from radiation_ppo_amd.rada2c import RNNAgentPPO, pack_episodes
+    parameters after two iterations.  The autograd path is handed the resampling INDICES the kernel took (as in
+    test_pfgru_training_kernel_matches_autograd: they are constants of the backward pass on both sides), so no discrete choice can
+    differ and EVERY parameter must agree within a quarter of an Adam step."""
+    from radiation_ppo_amd.rada2c import KernelDraws, RNNAgentPPO, pack_episodes
     g = torch.Generator().manual_seed(8)
     T, N = 30, 40
     obs = torch.rand(T, N, 11, generator=g).cuda()
@@ -303,20 +318,45 @@ def test_update_model_on_k13_equals_autograd_path():
     cut = (torch.rand(T, N, generator=g) < 0.1).to(torch.uint8)
     cut[-1] = 1
     B = pack_episodes(obs, act, z, z, z, src, cut.cuda(), n_total=N, seed=3)
-    res = []
+    res, taken = [], {}
     for k13 in (True, False):
         torch.manual_seed(6)
         ag = RNNAgentPPO(id=0, seed=1, train_pfgru_iters=2, episode_chunk=64)        # several chunks
         ag.use_k13 = k13
-        loss = ag.update_model(B)
-        res.append((loss, {k: v.detach().clone() for k, v in ag.agent.model.named_parameters()}))
+        if k13:
+            calls = []
+            orig = ag.model_pass_hip
+
+            def recording(Bx, sl, d, _orig=orig, _calls=calls):
+                out = _orig(Bx, sl, d)
+                _calls.append((sl.start, out[2].clone()))
+                return out
+            ag.model_pass_hip = recording
+            loss = ag.update_model(B)
+            n_chunks = len(calls) // 2
+            for i, (lo, idx) in enumerate(calls):
+                taken[(i // n_chunks, lo)] = idx
+        else:
+            def draws_for(it, sl):
+                kd = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0])
+                return _KernelIdxDraws(kd, taken[(it, sl.start)])
+            loss = ag.update_model(B, draws_for=draws_for)
+        res.append((loss, {k: v.detach().clone() for k, v in ag.agent.model.named_parameters()},
+                    {k: v.grad.detach().clone() for k, v in ag.agent.model.named_parameters()}))
     assert abs(res[0][0] - res[1][0]) <= 1e-3 * abs(res[1][0]), (res[0][0], res[1][0])
     lr = 5e-3
-    d = torch.cat([(res[0][1][k] - res[1][1][k]).abs().reshape(-1) for k in res[0][1]])
-    # an Adam step moves every element by ~lr: the same direction (almost) everywhere.  The two paths take their resampling indices
-    # from the same uniforms but evaluate the CDF with different exp implementations: a uniform within rounding of a CDF step may pick
-    # the neighbouring particle in one of them, which perturbs one episode's gradient -- hence "almost"
-    assert float((d <= 0.25 * lr).float().mean()) >= 0.97 and float(d.max()) <= 2 * 2 * lr, (float(d.max()), float((d <= 0.25 * lr).float().mean()))
+    gmax = max(float(v.abs().max()) for v in res[1][2].values())
+    n_noise = 0
+    for k in res[0][1]:
+        d = (res[0][1][k] - res[1][1][k]).abs()
+        # an Adam step is lr * m / (sqrt(v) + 1e-8): where the gradient is float32 rounding noise on both sides (fc_obs.bias: exactly
+        # 0 in exact arithmetic, see test_pfgru_training_kernel_matches_autograd) the step's sign is noise as well -- those
+        # elements, identified by their gradient, are counted and held to two full steps; everything else to a quarter step
+        noise = res[1][2][k].abs() <= 1e-6 * gmax
+        n_noise += int(noise.sum())
+        assert bool((d[~noise] <= 0.25 * lr).all()), (k, float(d[~noise].max()))
+        assert bool((d <= 2 * 2 * lr).all()), (k, float(d.max()))
+    assert n_noise <= 2, n_noise                                                      # fc_obs.bias and at most one more element
 
 
 def test_policy_step_kernel_matches_torch_composition():
