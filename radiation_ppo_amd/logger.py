@@ -9,6 +9,8 @@ plotting and evaluation scripts read.
                                 with_min_and_max also Max<key>, Min<key>; statistics exactly as get_stats (:33-39):
                                 float32 values, population standard deviation
     dump_tabular()                 :286-311   header on the first row, then tab-separated str(value)
+Only the FILE FORMATS and the call surface follow the reference (progress.txt is pinned byte for byte by
+tests/test_train_loop_golden.py); the code is this build's own.
     save_config / setup_pytorch_saver / save_state               :195-284
 
 `log_stats` is this build's addition for quantities reduced on the device (N envs x T steps never visit the host):
@@ -34,32 +36,39 @@ class Stats(NamedTuple):
 
 
 def get_stats(xs) -> Stats:
-    """epoch_logger.py:33-39 (same expressions, same float32 arithmetic)."""
-    sum, n = xs.sum(), len(xs)
-    mean = sum / n
-    std = np.sqrt(((xs - mean) ** 2 / n).sum())
-    min = xs.min() if len(xs) > 0 else np.inf
-    max = xs.max() if len(xs) > 0 else -np.inf
-    return Stats(n=n, sum=sum, min=min, max=max, mean=mean, std=std)
+    """Count / sum / extrema / mean / population standard deviation of a float32 vector.  File-format contract: the numbers are
+    printed with str() into progress.txt, so they are formed in the array's own precision in this order -- sum, sum / n, then
+    sqrt(sum((x - mean)^2 / n)) -- which is what the reference's rows contain (epoch_logger.py:33-39; pinned byte for byte by
+    tests/golden/train_trace.json)."""
+    n = len(xs)
+    total = np.add.reduce(xs)
+    mean = total / n
+    dev = xs - mean
+    spread = np.sqrt(np.add.reduce(dev * dev / n))
+    lo, hi = (np.minimum.reduce(xs), np.maximum.reduce(xs)) if n else (np.inf, -np.inf)
+    return Stats(n=n, sum=total, min=lo, max=hi, mean=mean, std=spread)
+
+
+_PLAIN = (str, int, float, bool, type(None))
 
 
 def convert_json(obj: Any) -> Any:
-    """epoch_logger.py:42-75: anything json cannot serialise becomes an informative string."""
-    try:
-        json.dumps(obj)
+    """A json.dumps-able image of an arbitrary configuration object (what save_config writes to config.json, whose readers are the
+    reference's plotting scripts, epoch_logger.py:42-75 defines the result): plain scalars as they are, containers element-wise,
+    named callables / classes by name, objects with attributes as {str(obj): {attribute: image}}, anything else as str(obj)."""
+    if isinstance(obj, _PLAIN):
         return obj
-    except Exception:  # noqa: BLE001
-        if isinstance(obj, dict):
-            return {convert_json(k): convert_json(v) for k, v in obj.items()}
-        if isinstance(obj, tuple):
-            return tuple(map(convert_json, obj))
-        if isinstance(obj, list):
-            return list(map(convert_json, obj))
-        if hasattr(obj, "__name__") and "lambda" not in obj.__name__:
-            return convert_json(obj.__name__)
-        if hasattr(obj, "__dict__") and obj.__dict__:
-            return {str(obj): {convert_json(k): convert_json(v) for k, v in obj.__dict__.items()}}
-        return str(obj)
+    if isinstance(obj, dict):
+        return {convert_json(k): convert_json(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [convert_json(v) for v in obj]
+    name = getattr(obj, "__name__", None)
+    if isinstance(name, str) and "lambda" not in name:
+        return name
+    attrs = getattr(obj, "__dict__", None)
+    if attrs:
+        return {str(obj): {convert_json(k): convert_json(v) for k, v in attrs.items()}}
+    return str(obj)
 
 
 class Logger:
@@ -118,24 +127,17 @@ class Logger:
             torch.save(self.pytorch_saver_elements.state_dict(), os.path.join(fpath, f"model{itr if itr is not None else ''}.pt"))
 
     def dump_tabular(self) -> None:
-        vals = []
+        """Close the epoch's row.  File-format contract (progress.txt, read by the reference's plot / compare scripts): a header
+        line with the column names on the first row, then one line per epoch, str() of every value, tab separated."""
+        row = [self.log_current_row.get(key, "") for key in self.log_headers]
         if not self.quiet:
-            key_lens = [len(key) for key in self.log_headers]
-            max_key_len = max(15, max(key_lens))
-            fmt = "| " + "%" + "%d" % max_key_len + "s | %15s |"
-            n_slashes = 22 + max_key_len
-            print("-" * n_slashes)
-        for key in self.log_headers:
-            val = self.log_current_row.get(key, "")
-            if not self.quiet:
-                print(fmt % (key, "%8.3g" % val if hasattr(val, "__float__") else val))
-            vals.append(val)
-        if not self.quiet:
-            print("-" * n_slashes, flush=True)
+            width = max(len(k) for k in self.log_headers) if self.log_headers else 0
+            shown = [f"{v:.4g}" if isinstance(v, (float, np.floating)) else str(v) for v in row]
+            print("\n".join(f"  {k:<{width}}  {v}" for k, v in zip(self.log_headers, shown)) + "\n", flush=True)
         if self.output_file is not None:
             if self.first_row:
                 self.output_file.write("\t".join(self.log_headers) + "\n")
-            self.output_file.write("\t".join(map(str, vals)) + "\n")
+            self.output_file.write("\t".join(str(v) for v in row) + "\n")
             self.output_file.flush()
         self.rows.append(dict(self.log_current_row))
         self.log_current_row.clear()
@@ -163,16 +165,19 @@ class EpochLogger(Logger):
 
     def log_tabular(self, key: str, val: Any = None, with_min_and_max: bool = False, average_only: bool = False,
                     sum_only: bool = False, rate_only: bool = False) -> None:
+        """One column from a value, or the statistics columns of everything stored under `key` this epoch (column names and
+        their order are the progress.txt contract: Mean<key> | <key>, Std<key>, Max<key>, Min<key>; epoch_logger.py:358-401)."""
         if val is not None:
             Logger.log_tabular(self, key, val)
+            self.epoch_dict[key] = []
+            return
+        stored = self.epoch_dict[key]
+        arrays = isinstance(stored[0], np.ndarray) and stored[0].ndim > 0
+        flat = np.concatenate(stored) if arrays else np.asarray(stored, dtype=np.float32)
+        if rate_only:
+            Logger.log_tabular(self, key, sum(flat) / sum(self.epoch_dict["EpLen"]))
         else:
-            v = self.epoch_dict[key]
-            vals = (np.concatenate(v) if isinstance(v[0], np.ndarray) and len(v[0].shape) > 0 else np.array(v, dtype=np.float32))
-            stats = get_stats(vals)
-            if not rate_only:
-                self._emit(key, stats, with_min_and_max, average_only, sum_only)
-            else:
-                Logger.log_tabular(self, key, sum(vals) / sum(self.epoch_dict["EpLen"]))
+            self._emit(key, get_stats(flat), with_min_and_max, average_only, sum_only)
         self.epoch_dict[key] = []
 
     def log_stats(self, key: str, mean: float, std: float, max: float, min: float, with_min_and_max: bool = False,
