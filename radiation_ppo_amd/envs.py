@@ -118,6 +118,24 @@ class RadSearchVec:
                 "collision": self.collision}
         return self.obs, self.reward, self.team, self.done, info
 
+    _OUTS = ("obs", "reward", "team", "done", "oob", "oob_count", "blocked", "collision")
+
+    def snapshot(self) -> Dict[str, torch.Tensor]:
+        """A copy of the whole env state (the handle's workspace: positions, sources, rectangles, cached geodesics, Philox
+        counters, latches) and of the output rows -- what a resumed run restores (train_PPO.load)."""
+        st = {"ws": self._ws[self._ws_off:self._ws_off + self.lib.rs_state_bytes(C.byref(self.cfg))].clone()}
+        st.update({k: getattr(self, k).clone() for k in self._OUTS})
+        return st
+
+    def restore(self, st: Dict[str, torch.Tensor]) -> None:
+        """Inverse of snapshot() for an env of the same configuration (in place: captured graphs keep their addresses)."""
+        n = self.lib.rs_state_bytes(C.byref(self.cfg))
+        if st["ws"].numel() != n:
+            raise ValueError("RadSearchVec.restore: the snapshot belongs to another configuration")
+        self._ws[self._ws_off:self._ws_off + n].copy_(st["ws"])
+        for k in self._OUTS:
+            getattr(self, k).copy_(st[k])
+
     # ------------------------------------------------------------------ API
     def set_epoch_end(self) -> None:
         """`env.epoch_end = True` for every env (algos/multiagent/train.py:482-484)."""

@@ -53,6 +53,7 @@ class HeatMaps:
             raise ValueError("invalid heat-map configuration")
         self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         self._ws_base = self._ws.data_ptr() + (-self._ws.data_ptr()) % 256
+        self._ws_span = (self._ws_base - self._ws.data_ptr(), nbytes)
         h = C.c_void_p()
         _lib.check(self.lib.rs_maps_create(self.N, self.A, self.L, X, Y, float(self.resolution_accuracy),
                                            self.visit_table.data_ptr(), self._ws_base, nbytes, env._stream(), C.byref(h)),
@@ -66,6 +67,17 @@ class HeatMaps:
         if h:
             self.lib.rs_maps_destroy(h)
             self._h = None
+
+    def snapshot(self) -> torch.Tensor:
+        """A copy of the heat-map state of every env (maps, reading rings, cells, Welford state): what a resumed run restores."""
+        o, n = self._ws_span
+        return self._ws[o:o + n].clone()
+
+    def restore(self, ws: torch.Tensor) -> None:
+        o, n = self._ws_span
+        if ws.numel() != n:
+            raise ValueError("HeatMaps.restore: the snapshot belongs to another configuration")
+        self._ws[o:o + n].copy_(ws)
 
     def field(self, name: str) -> torch.Tensor:
         p, e, r, c = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()

@@ -315,6 +315,17 @@ class PredictorBank:
         self.calls.add_(1 if mask is None else mask.long())
         return loc.permute(1, 0, 2).contiguous()
 
+    def resume_state(self):
+        """Particle sets and draw counters (the cells' weights are saved with the agents)."""
+        return dict(h=self.h.clone(), p=self.p.clone(), episode=self.episode.clone(), calls=self.calls.clone())
+
+    def load_resume_state(self, st) -> None:
+        if self.impl == "hip":                                     # in place: a captured collector step refers to these tensors
+            self.h.copy_(st["h"]); self.p.copy_(st["p"])
+        else:
+            self.h, self.p = st["h"].clone(), st["p"].clone()
+        self.episode.copy_(st["episode"]); self.calls.copy_(st["calls"])
+
     def state_dict(self, a: int):
         return self.cells[a].state_dict()
 

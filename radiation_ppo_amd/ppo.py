@@ -417,7 +417,7 @@ class VecAgentPPO:
         torch.save(self.agent.state_dict(), path)
 
     def load(self, path: str) -> None:
-        self.agent.load_state_dict(torch.load(path, map_location=self.device))
+        self.agent.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
 
     def resume_state(self) -> Dict[str, Any]:
         """Everything a resumed run needs beyond the weights (absent in the reference): Adam moments and step
@@ -517,6 +517,14 @@ class EpochStats:
                     EpRetSum=self.ret_sum.clone(), EpRetSqSum=self.ret_sq.clone(), EpRetMax=self.ret_max.clone(), EpRetMin=self.ret_min.clone())
 
 
+def _welford_state(w: "DeviceWelford"):
+    return dict(count=w.count.clone(), mean=w.mean.clone(), sq=w.sq.clone(), std=w.std.clone())
+
+
+def _welford_load(w: "DeviceWelford", st) -> None:
+    w.count.copy_(st["count"]); w.mean.copy_(st["mean"]); w.sq.copy_(st["sq"]); w.std.copy_(st["std"])
+
+
 class Collector:
     """The epoch loop body of train_PPO.train (train.py:332-548) for N envs at once: policy forward,
     Philox inverse-CDF sampling, env lock-step, buffer write, episode/epoch cut logic, bootstrap values,
@@ -609,6 +617,20 @@ class Collector:
     def update(self) -> Dict[int, UpdateResult]:
         return ppo_update_from_buffer(self)
 
+    # what a run carries from one epoch into the next (train_PPO.save_resume / load): the env and the running episode state
+    def resume_state(self) -> Dict[str, Any]:
+        if not self.started:
+            self.start()
+        return dict(env=self.env.snapshot(), stat=_welford_state(self.stat), steps_in_ep=self.steps_in_ep.clone(),
+                    ep_ret=self.ep_ret.clone(), obs=self.obs.clone())
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        if not self.started:
+            self.start()
+        self.env.restore(st["env"])
+        _welford_load(self.stat, st["stat"])
+        self.steps_in_ep, self.ep_ret, self.obs = st["steps_in_ep"].clone(), st["ep_ret"].clone(), st["obs"].clone()
+
 
 class FusedCollector:
     """Same contract as Collector, but the whole epoch is ONE kernel launch (rs_rollout): MLP forward on
@@ -676,6 +698,20 @@ class FusedCollector:
 
     def update(self) -> Dict[int, UpdateResult]:
         return ppo_update_from_buffer(self)
+
+    _RESUME = ("cur_obs", "w_count", "w_mean", "w_sq", "w_std", "steps_in_ep", "ep_ret")
+
+    def resume_state(self) -> Dict[str, Any]:
+        if not self.started:
+            self.start()
+        return dict(env=self.env.snapshot(), **{k: getattr(self, k).clone() for k in self._RESUME})
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        if not self.started:
+            self.start()
+        self.env.restore(st["env"])
+        for k in self._RESUME:
+            getattr(self, k).copy_(st[k])                          # in place: rs_rollout's argument block holds their addresses
 
 
 def ppo_update_from_buffer(col) -> Dict[int, UpdateResult]:

@@ -184,20 +184,25 @@ class CNNAgentPPO:
         for mod, name in ((self.pi, "actor.pt"), (self.critic, "critic.pt")):
             f = os.path.join(path, name)
             assert os.path.isfile(f), "Model does not exist"
-            mod.load_state_dict(torch.load(f, map_location=self.device))
+            mod.load_state_dict(torch.load(f, map_location=self.device, weights_only=True))
         f = os.path.join(path, "predictor.pt")
         if getattr(self, "model", None) is not None and os.path.isfile(f):
-            self.model.load_state_dict(torch.load(f, map_location=self.device))
+            self.model.load_state_dict(torch.load(f, map_location=self.device, weights_only=True))
 
     def resume_state(self) -> Dict[str, Any]:
-        return dict(actor=self.pi.state_dict(), critic=self.critic.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
-                    critic_optimizer=self.critic_optimizer.state_dict(), pi_scheduler=self.pi_scheduler.state_dict(),
-                    critic_scheduler=self.critic_scheduler.state_dict())
+        st = dict(actor=self.pi.state_dict(), critic=self.critic.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
+                  critic_optimizer=self.critic_optimizer.state_dict(), pi_scheduler=self.pi_scheduler.state_dict(),
+                  critic_scheduler=self.critic_scheduler.state_dict())
+        if getattr(self, "model", None) is not None:               # the (untrained) predictor whose output fills heat-map channel 0
+            st["model"] = self.model.state_dict()
+        return st
 
     def load_resume_state(self, st: Dict[str, Any]) -> None:
         self.pi.load_state_dict(st["actor"]); self.critic.load_state_dict(st["critic"])
         self.pi_optimizer.load_state_dict(st["pi_optimizer"]); self.critic_optimizer.load_state_dict(st["critic_optimizer"])
         self.pi_scheduler.load_state_dict(st["pi_scheduler"]); self.critic_scheduler.load_state_dict(st["critic_scheduler"])
+        if "model" in st and getattr(self, "model", None) is not None:
+            self.model.load_state_dict(st["model"])
 
 
 class CNNCollector:
@@ -365,6 +370,29 @@ class CNNCollector:
         self._step(True)
         self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
         return self._acc.result()
+
+    def resume_state(self) -> Dict[str, Any]:
+        if self.obs is None:
+            self.start()
+        return dict(env=self.env.snapshot(), maps=self.maps.snapshot(), steps_in_ep=self.steps_in_ep.clone(), ep_ret=self.ep_ret.clone(),
+                    obs=self.obs.clone(), predictor=None if self.predictor is None else self.predictor.resume_state())
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        if self.obs is None:
+            self.start()
+        self.env.restore(st["env"]); self.maps.restore(st["maps"])
+        self.steps_in_ep.copy_(st["steps_in_ep"]); self.ep_ret.copy_(st["ep_ret"]); self.obs.copy_(st["obs"])
+        if self.predictor is not None and st.get("predictor") is not None:
+            self.predictor.load_resume_state(st["predictor"])
+
+    def sync_predictors(self) -> None:
+        """Rank 0's predictor cells for every rank (they are created from each process' own torch generator): the per-owner
+        PFGRU fills heat-map channel 0 and only rank 0's predictor.pt is saved."""
+        if self.predictor is None or _world() == 1:
+            return
+        for cell in self.predictor.cells:
+            for p_ in cell.parameters():
+                dist.broadcast(p_.data, src=0)
 
     def update(self) -> Dict[int, UpdateResult]:
         buf, T, N = self.buf, self.T, self.N

@@ -818,7 +818,7 @@ class RNNAgentPPO:
 
     def load(self, path: str) -> None:
         import os
-        self.agent.load_state_dict(torch.load(os.path.join(path, "pyt_save", "model.pt"), map_location=self.device))
+        self.agent.load_state_dict(torch.load(os.path.join(path, "pyt_save", "model.pt"), map_location=self.device, weights_only=True))
 
     def resume_state(self) -> Dict[str, Any]:
         return dict(agent=self.agent.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(), model_optimizer=self.model_optimizer.state_dict(),
@@ -1013,6 +1013,25 @@ class RNNCollector:
         self._step(True)
         self.buf.finish(self.agents[0].gamma, self.agents[0].lam)
         return self._acc.result()
+
+    def resume_state(self) -> Dict[str, Any]:
+        from .ppo import _welford_state
+        if not self.started:
+            self.start()
+        return dict(env=self.env.snapshot(), stat=_welford_state(self.stat), steps_in_ep=self.steps_in_ep.clone(), ep_ret=self.ep_ret.clone(),
+                    obs=self.obs.clone(), h=self.h.clone(), bank=self.bank.resume_state(), episodes_begun=self.episodes_begun.clone(),
+                    epoch=self.epoch)
+
+    def load_resume_state(self, st: Dict[str, Any]) -> None:
+        from .ppo import _welford_load
+        if not self.started:
+            self.start()
+        self.env.restore(st["env"])
+        _welford_load(self.stat, st["stat"])
+        self.steps_in_ep.copy_(st["steps_in_ep"]); self.ep_ret.copy_(st["ep_ret"]); self.obs.copy_(st["obs"]); self.h.copy_(st["h"])
+        self.bank.load_resume_state(st["bank"])
+        self.episodes_begun.copy_(st["episodes_begun"])
+        self.epoch = int(st["epoch"])                                         # keys every update draw
 
     def update(self) -> Dict[int, UpdateResult]:
         buf = self.buf

@@ -124,6 +124,7 @@ class train_PPO:
                                           global_critic_flag=self.global_critic_flag,
                                           use_predictor=bool(kw.get("use_predictor", True)),
                                           predictor_hidden_size=int(kw.get("predictor_hidden_size", 24)))
+            self.collector.sync_predictors()                   # created after sync_params, from each rank's own generator
             return
         if self.actor_critic_architecture == "rnn":                           # RAD-A2C: GRU actor-critic + PFGRU (rada2c.py)
             kw.setdefault("seed", self.seed)
@@ -163,12 +164,17 @@ class train_PPO:
         for i, ag in self.agents.items():
             d = self.loggers[i].output_dir
             if d:
-                torch.save(dict(agent=ag.resume_state(), epochs_done=self.epochs_done, torch_rng=torch.get_rng_state()),
-                           os.path.join(d, "resume.pt"))
+                st = dict(agent=ag.resume_state(), epochs_done=self.epochs_done, torch_rng=torch.get_rng_state())
+                if i == min(self.agents):
+                    # the env and the collector's running episode state (Philox counters, Welford / heat-map / particle state,
+                    # episode and epoch counters that key the draws): with them a resumed run IS the uninterrupted one
+                    st["collector"] = self.collector.resume_state()
+                torch.save(st, os.path.join(d, "resume.pt"))
 
     def load(self, directory: str) -> None:
-        """Resume from agent directories `<directory>/<id>_agent...` written by save() (weights, optimiser moments, step counts,
-        LR-schedule position).  The env's Philox streams are keyed by (seed, env id, episode): nothing else to restore."""
+        """Resume from agent directories `<directory>/<id>_agent...` written by save_resume(): weights, optimiser moments, step
+        counts, LR-schedule position, and -- from the first agent's file -- the env state, the collector's running episode state
+        and the host generator, so that the resumed run continues the saved one draw for draw (tests/test_train_logging_gpu.py)."""
         for i, ag in self.agents.items():
             cands = [os.path.join(directory, n) for n in sorted(os.listdir(directory)) if n.startswith(f"{i}_agent")]
             hits = ([c for c in cands if os.path.exists(os.path.join(c, "resume.pt"))]
@@ -176,9 +182,13 @@ class train_PPO:
                         if os.path.exists(os.path.join(c, s, "resume.pt"))])
             if not hits:
                 raise FileNotFoundError(f"no resume.pt for agent {i} under {directory}")
-            st = torch.load(os.path.join(hits[0], "resume.pt"), map_location=self.vec.device)
+            # tensors, containers and plain scalars only: the restricted loader suffices
+            st = torch.load(os.path.join(hits[0], "resume.pt"), map_location=self.vec.device, weights_only=True)
             ag.load_resume_state(st["agent"])
             self.epochs_done = int(st["epochs_done"])
+            if "collector" in st:
+                self.collector.load_resume_state(st["collector"])
+                torch.set_rng_state(st["torch_rng"].cpu())
 
     # ------------------------------------------------------------------ the loop
     def train(self) -> None:

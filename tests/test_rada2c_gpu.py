@@ -353,10 +353,10 @@ def test_update_model_on_k13_equals_autograd_path():
         # 0 in exact arithmetic, see test_pfgru_training_kernel_matches_autograd) the step's sign is noise as well -- those
         # elements, identified by their gradient, are counted and held to two full steps; everything else to a quarter step
         noise = res[1][2][k].abs() <= 1e-6 * gmax
-        n_noise += int(noise.sum())
+        n_noise += int((noise & (d > 0.25 * lr)).sum())
         assert bool((d[~noise] <= 0.25 * lr).all()), (k, float(d[~noise].max()))
         assert bool((d <= 2 * 2 * lr).all()), (k, float(d.max()))
-    assert n_noise <= 2, n_noise                                                      # fc_obs.bias and at most one more element
+    assert n_noise <= 2, n_noise                        # elements beyond a quarter step: fc_obs.bias and at most one more noise element
 
 
 def test_policy_step_kernel_matches_torch_composition():

@@ -114,3 +114,40 @@ def test_cnn_rejects_unenforced_boundaries_up_front():
     env = RadSearchVec(4, number_agents=1, obstruction_count=0, enforce_grid_boundaries=False, seed=1)
     with pytest.raises(NotImplementedError, match="27 x 27"):
         train_PPO(env=env, logger_kwargs={}, number_of_agents=1, global_critic_flag=False, steps_per_epoch=8, steps_per_episode=4)
+
+
+@pytest.mark.parametrize("arch", ["ff", "rnn", "cnn"])
+def test_resumed_run_equals_the_uninterrupted_run(tmp_path, arch):
+    """3 epochs in one go against 2 epochs, save_resume, a fresh process-worth of objects (new env, agents, collector), load, 1 more
+    epoch: resume.pt restores the env workspace (Philox counters, sources, rectangles), the collector's running episode state
+    (Welford / heat maps / particle sets / GRU states / episode and epoch counters that key the update draws), optimiser moments
+    and the host generator, so the third epoch's rollout buffer and the final parameters are IDENTICAL."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.train import train_PPO
+    A = 2 if arch == "cnn" else 1
+    kw = dict(seed=7, number_of_agents=A, actor_critic_architecture=arch, global_critic_flag=(arch == "cnn"), steps_per_epoch=20,
+              steps_per_episode=8, save_freq=1,
+              ppo_kwargs=dict(train_pi_iters=2, train_v_iters=2, train_pfgru_iters=2, alpha=0.1))
+
+    def make(out, epochs):
+        env = RadSearchVec(16, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=11)
+        return train_PPO(env=env, logger_kwargs=dict(output_dir=str(out)), total_epochs=epochs, **kw)
+
+    def params(sim):
+        mods = []
+        for ag in sim.agents.values():
+            mods += [ag.pi, ag.critic, ag.model] if arch == "cnn" else [ag.agent]
+        return torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()])
+
+    whole = make(tmp_path / "whole", 3)
+    whole.train()
+    first = make(tmp_path / "first", 2)
+    first.train()
+    second = make(tmp_path / "second", 3)
+    second.load(str(tmp_path / "first"))
+    assert second.epochs_done == 2
+    second.train()
+    for k in ("obs", "act", "rew", "val", "logp", "cut", "adv", "ret"):
+        assert torch.equal(getattr(whole.collector.buf, k), getattr(second.collector.buf, k)), k
+    assert torch.equal(params(whole), params(second))
+    assert whole.loggers[0].rows[-1]["loss_policy"] == second.loggers[0].rows[-1]["loss_policy"]
