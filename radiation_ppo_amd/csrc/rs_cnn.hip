@@ -6,9 +6,12 @@
 // peak on these shapes), so the trunk is written directly:
 //   * one image per 192-thread workgroup at a time, the whole image in LDS (zero-padded planes), workgroups
 //     stride over the batch (persistent grid);
-//   * the input stack is never materialised in HBM: the 4 shared maps of a sample are read once (11.7 KB) and
-//     the owner's location / prediction one-hots and `others = combined - location`
-//     (CNNBase.get_map_stack, RADTEAM_core.py:1791-1836) are formed in LDS;
+//   * the input stack is never materialised in HBM: the 4 shared maps of a sample are read once (11.7 KB).  Of the actor's six
+//     channels (CNNBase.get_map_stack, RADTEAM_core.py:1791-1836) only these four are dense; the owner's prediction and location
+//     maps are ONE-HOT and `others = combined - location`, so conv1 runs over the 4 dense planes (`combined` with the weights of
+//     `others`) and the one-hots enter as 3x3 weight STAMPS on the <= 9 output pixels around the owner's cell
+//     (w1[:, pred] at the prediction cell, w1[:, loc] - w1[:, others] at the location cell): 2 of 6 channels of conv1 and of dW1 are
+//     not convolved at all.  Backward, the same channels' weight gradients are 9-element gathers of dZ1 (through the pool's arg-max);
 //   * conv1 is evaluated per POOLED cell (thread = cell: a 4x4 input window per channel in registers feeds the
 //     2x2 block of conv outputs, 8 channels each -> 32 accumulators), so ReLU + max-pool happen in registers;
 //     row/column 26 of the conv1 output never reach the pool (27 = 2*13 + 1) and are not computed;
@@ -43,8 +46,11 @@ constexpr int CNN_NT_BWD = CNN_NTB;         // backward: a 4th wave that owns no
                                             // the dW1 gathers -- the kernel is wait-bound (56 % of its wave cycles parked), not VALU-bound
 constexpr int MAPW = 27, MAPC = 729;        // heat-map side and cells
 constexpr int PW = 13, PC = 169;            // pooled side and cells
-constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 6;   // (+6: see the bank map of the dW1 gather in rs_cnn_bwd_kernel)   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
+constexpr int DP = 4;                       // dense input planes in LDS: combined, readings, visits, obstacles (actor and critic alike)
+constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 6;   // padded input plane: xp[r][c] = x[r-1][c-1], r,c in [0,28): the bottom/right
                                                 // border only feeds conv1 row/column 26, which the pool drops; even stride (b64 reads)
+constexpr int XP_PLANE_B = 28 * 28 + 7;         // backward: ODD plane stride -- the dW1 gather's two channel halves (2 planes apart) must
+                                                // land in the other 16 LDS banks (see the bank map in rs_cnn_bwd_kernel)
 constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
 
@@ -53,7 +59,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // v_fma's SGPR operand, so they cost neither LDS return bandwidth nor VGPRs.  (Broadcast ds_reads still return
 // 64 x 16 B per wave and made conv2 / dP1 LDS-bound.)  The scalar loads want [tap][channel] rows, produced once per
 // call by rs_cnn_prep_kernel into a caller-provided scratch:
-//   [w1t (Cin*9) x 8 | b1 8 | w2t 72 x 16 | b2 16 | w2b (co,ky,kx)=144 x 8 ci]
+//   [w1t (Cin*9) x 8 | b1 8 | w2t 72 x 16 | b2 16 | w2b (co,ky,kx)=144 x 8 ci | stamps 2 x 9 x 8 (actor: prediction, location)]
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 constexpr int WT_W1(int) { return 0; }
@@ -61,7 +67,8 @@ constexpr int WT_B1(int cin) { return cin * 9 * 8; }
 constexpr int WT_W2(int cin) { return cin * 9 * 8 + 8; }
 constexpr int WT_B2(int cin) { return cin * 9 * 8 + 8 + 72 * 16; }
 constexpr int WT_W2B(int cin) { return cin * 9 * 8 + 8 + 72 * 16 + 16; }
-constexpr int WT_TOTAL(int cin) { return cin * 9 * 8 + 8 + 72 * 16 + 16 + 144 * 8; }
+constexpr int WT_ST(int cin) { return cin * 9 * 8 + 8 + 72 * 16 + 16 + 144 * 8; }
+constexpr int WT_TOTAL(int cin) { return WT_ST(cin) + 2 * 9 * 8; }
 
 __global__ void rs_cnn_prep_kernel(int cin, const float* __restrict__ w1, const float* __restrict__ b1,
                                    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ wt) {
@@ -76,6 +83,12 @@ __global__ void rs_cnn_prep_kernel(int cin, const float* __restrict__ w1, const 
         const int ci = k / 9, kk = k - ci * 9;
         wt[WT_W2B(cin) + (co * 9 + kk) * 8 + ci] = w2[e];                 // [(co,ky,kx)][ci]
     }
+    if (w1 && cin == 6)
+        for (int e = threadIdx.x; e < 72; e += blockDim.x) {                 // [tap][co]: what a one-hot input adds to conv1's output
+            const int kk = e / 8, co = e - kk * 8;
+            wt[WT_ST(cin) + e] = w1[(co * 6 + 0) * 9 + kk];                                   // prediction map (channel 0)
+            wt[WT_ST(cin) + 72 + e] = w1[(co * 6 + 1) * 9 + kk] - w1[(co * 6 + 2) * 9 + kk];  // location (1) minus its share of `others` (2)
+        }
     if (threadIdx.x < 8) wt[WT_B1(cin) + threadIdx.x] = b1 ? b1[threadIdx.x] : 0.0f;
     if (threadIdx.x < 16) wt[WT_B2(cin) + threadIdx.x] = b2 ? b2[threadIdx.x] : 0.0f;
 }
@@ -89,21 +102,28 @@ struct CnnIn {
 };
 
 // ---- one sample's inputs travel HBM -> registers -> LDS; the registers of sample s+grid are filled while sample s
-// is being computed (software prefetch), so the per-image memory latency is off the critical path
+// is being computed (software prefetch), so the per-image memory latency is off the critical path.
+// Mapping: the 4 x 27 map rows of a sample are 108 contiguous rows of 27 floats.  G = NT / 27 thread groups of 27 threads
+// (thread = column c of its group's rows p = g, g + G, ...): the global index is tid + i * 27 G (contiguous across the active
+// threads), and the padded LDS address advances by a constant per row with one wrap test per element -- a first version
+// decomposed every element index with four divisions by constants, 19 % of K9's instructions.
 template <int NT>
 struct CnnFetch {
-    static constexpr int PER_THREAD = (4 * MAPC + NT - 1) / NT;         // 16 (NT = 192) / 12 (NT = 256)
+    static constexpr int G = NT / MAPW;                                 // 7 (NT = 192) / 9 (NT = 256)
+    static constexpr int PER_THREAD = (4 * MAPW + G - 1) / G;           // 16 / 12 rows per thread
     float m[PER_THREAD];
     int loc, pc;
 };
 
 template <int CIN, int NT>
 __device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch<NT>& f) {
+    constexpr int G = CnnFetch<NT>::G;
     const float* src = in.maps + (size_t)s * 4 * MAPC;
+    const bool active = threadIdx.x < G * MAPW;
 #pragma unroll
     for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
-        const int e = threadIdx.x + i * NT;
-        f.m[i] = (e < 4 * MAPC) ? src[e] : 0.0f;
+        const int e = threadIdx.x + i * G * MAPW;
+        f.m[i] = (active && e < 4 * MAPC) ? src[e] : 0.0f;
     }
     f.loc = -1; f.pc = -1;
     if (CIN == 6) {
@@ -112,43 +132,17 @@ __device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch
     }
 }
 
-template <int CIN, int NT>
+template <int PLANE, int NT>
 __device__ __forceinline__ void cnn_stage(const CnnFetch<NT>& f, float* xp) {
-    constexpr int CH0 = (CIN == 6) ? 2 : 0;
+    constexpr int G = CnnFetch<NT>::G;
+    const int g = threadIdx.x / MAPW, c = threadIdx.x - g * MAPW;
+    const bool active = g < G;
+    int r = g, dst = (g + 1) * XP_RS + c + 1;                           // row p = g of plane 0
 #pragma unroll
     for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
-        const int e = threadIdx.x + i * NT;
-        if (e < 4 * MAPC) {
-            const int m = e / MAPC, q = e - m * MAPC;
-            const int r = q / MAPW, c = q - r * MAPW;
-            xp[(CH0 + m) * XP_PLANE + (r + 1) * XP_RS + (c + 1)] = f.m[i];
-        }
-    }
-}
-
-// the owner's one-hots (after the planes are in place)
-template <int CIN>
-__device__ __forceinline__ void cnn_set_onehots(float* xp, int loc, int pc) {
-    if (CIN == 6 && threadIdx.x == 0) {
-        const int lr = loc / MAPW, lc = loc - lr * MAPW;
-        xp[1 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] = 1.0f;          // location map
-        xp[2 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] -= 1.0f;         // others = combined - location
-        if (pc >= 0) {
-            const int pr = pc / MAPW, pcc = pc - pr * MAPW;
-            xp[0 * XP_PLANE + (pr + 1) * XP_RS + pcc + 1] = 1.0f;      // prediction map
-        }
-    }
-}
-
-template <int CIN>
-__device__ __forceinline__ void cnn_clear_onehots(float* xp, int loc, int pc) {
-    if (CIN == 6 && threadIdx.x == 0) {
-        const int lr = loc / MAPW, lc = loc - lr * MAPW;
-        xp[1 * XP_PLANE + (lr + 1) * XP_RS + lc + 1] = 0.0f;
-        if (pc >= 0) {
-            const int pr = pc / MAPW, pcc = pc - pr * MAPW;
-            xp[0 * XP_PLANE + (pr + 1) * XP_RS + pcc + 1] = 0.0f;
-        }
+        if (active && g + i * G < 4 * MAPW) xp[dst] = f.m[i];
+        r += G; dst += G * XP_RS;
+        if (r >= MAPW) { r -= MAPW; dst += PLANE - MAPW * XP_RS; }      // into the next plane (G < 27: one wrap at most)
     }
 }
 
@@ -161,12 +155,15 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
                                                             float* __restrict__ p1g, uint8_t* __restrict__ amax,
                                                             uint16_t* __restrict__ relu_mask) {
     extern __shared__ __align__(16) float smem[];
-    float* xp = smem;                               // [CIN][28][28]
-    float* pp = xp + CIN * XP_PLANE;                // [8][15][15]
-    const cmem_t w1c = as_cmem(wt + WT_W1(CIN)), b1c = as_cmem(wt + WT_B1(CIN));
+    float* xp = smem;                               // [4 dense planes][28][28]
+    float* pp = xp + DP * XP_PLANE;                 // [8][15][15]
+    float* stl = pp + C1 * PP_PLANE;                // [2][9][8] actor: the one-hot channels' weight stamps
+    constexpr int CH0 = (CIN == 6) ? 2 : 0;         // the logical channel of dense plane 0 (actor: `others`, convolved as `combined`)
+    const cmem_t w1c = as_cmem(wt + WT_W1(CIN) + CH0 * 9 * C1), b1c = as_cmem(wt + WT_B1(CIN));
     const cmem_t w2c = as_cmem(wt + WT_W2(CIN)), b2c = as_cmem(wt + WT_B2(CIN));
     const int tid = threadIdx.x;
-    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;     // borders stay zero
+    for (int e = tid; e < DP * XP_PLANE + C1 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;      // borders stay zero
+    if (CIN == 6 && tid < 2 * 9 * C1) stl[tid] = wt[WT_ST(CIN) + tid];
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
@@ -174,9 +171,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
     if ((long long)blockIdx.x < in.S) cnn_fetch<CIN, CNN_NT>(in, blockIdx.x, f);
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
         const int loc = f.loc, pc = f.pc;
-        cnn_stage<CIN, CNN_NT>(f, xp);
-        __syncthreads();
-        cnn_set_onehots<CIN>(xp, loc, pc);
+        cnn_stage<XP_PLANE, CNN_NT>(f, xp);
         if (s + gridDim.x < in.S) cnn_fetch<CIN, CNN_NT>(in, s + gridDim.x, f);      // next sample: in flight during the compute
         __syncthreads();
         if (own) {
@@ -187,7 +182,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
 #pragma unroll
                 for (int co = 0; co < C1; ++co) acc[p][co] = 0.0f;
 #pragma unroll 1       // one input channel at a time: bounds the live broadcast weights (18 float4) and the window
-            for (int ci = 0; ci < CIN; ++ci) {
+            for (int ci = 0; ci < DP; ++ci) {
                 float win[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -217,6 +212,30 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
                                 }
                             }
                     }
+            }
+            if (CIN == 6) {
+                // the one-hot channels: a 1 at input (r, c) adds w[ky][kx] to conv output (r - ky + 1, c - kx + 1); at most four cells
+                // of the image own such a pixel (loc / pc are workgroup-uniform: the range test is two scalar compares)
+                auto stamp = [&](int cell, const float* ws) {
+                    const int r = cell / MAPW, c = cell - r * MAPW;
+                    const int dy = r - 2 * py, dx = c - 2 * px;
+                    if (dy >= -1 && dy <= 2 && dx >= -1 && dx <= 2) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int ky = dy - i + 1, kx = dx - j + 1;
+                                if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) {
+                                    const v4f wa = *reinterpret_cast<const v4f*>(ws + (ky * 3 + kx) * C1);
+                                    const v4f wb = *reinterpret_cast<const v4f*>(ws + (ky * 3 + kx) * C1 + 4);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) { acc[i * 2 + j][q] += wa[q]; acc[i * 2 + j][4 + q] += wb[q]; }
+                                }
+                            }
+                    }
+                };
+                stamp(loc, stl + 72);
+                if (pc >= 0) stamp(pc, stl);
             }
             float pbest[C1];
             uint32_t pidx[2] = {0u, 0u};
@@ -266,7 +285,6 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
             }
             if (relu_mask) relu_mask[(size_t)s * PC + tid] = (uint16_t)live;       // what backward needs of a2: its sign
         }
-        cnn_clear_onehots<CIN>(xp, loc, pc);
         __syncthreads();
     }
 }
@@ -280,8 +298,8 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                                                             const uint8_t* __restrict__ amax, float* __restrict__ slab) {
     extern __shared__ __align__(16) float smem[];
     constexpr int K1 = CIN * 9;
-    float* xp = smem;                               // [CIN][28][28]
-    float* pp = xp + CIN * XP_PLANE;                // [8][15][15]   padded P1
+    float* xp = smem;                               // [4 dense planes][28][28] (plane stride XP_PLANE_B)
+    float* pp = xp + DP * XP_PLANE_B;               // [8][15][15]   padded P1
     float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
     float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
     uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [169][8]
@@ -289,7 +307,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVE = CNN_NT_BWD / 64;
-    for (int e = tid; e < CIN * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
+    for (int e = tid; e < DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
@@ -297,17 +315,22 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     v4f accw[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) accw[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-    // dW1: thread = (output channel co1, half of the input channels) x one of 12 cell groups: per cell three index reads
-    // (gradient, arg-max, cell offset) feed CG*9 window reads + FMAs (+ db1 on the first-half threads)
-    constexpr int CG = CIN / 2, NCOMBO = C1 * 2, NGRP = CNN_NT_BWD / NCOMBO, AW = CG * 9 + 1;     // 16 combos x (threads / 16) groups
+    // dW1 of the DENSE planes: thread = (output channel co1, half of the 4 planes) x one of 16 cell groups: per cell three index reads
+    // (gradient, arg-max, cell offset) feed CG*9 window reads + FMAs (+ db1 on the first-half threads).  The actor's one-hot
+    // channels take their weight gradients from 9-element gathers instead (gst below).
+    constexpr int CG = DP / 2, NCOMBO = C1 * 2, NGRP = CNN_NT_BWD / NCOMBO, AW = CG * 9 + 1;     // 16 combos x (threads / 16) groups
+    float gst = 0.0f;                               // actor: thread (which, co, tap) of the 2 x 8 x 9 stamp gradients, tid < 144
+    const int st_which = tid / (C1 * 9), st_co = (tid - st_which * (C1 * 9)) / 9, st_kk = tid % 9;
+    const int st_dy = 1 - st_kk / 3, st_dx = 1 - st_kk % 3;
     float aw1[AW];
 #pragma unroll
     for (int k = 0; k < AW; ++k) aw1[k] = 0.0f;
     const int combo = tid % NCOMBO, grp = tid / NCOMBO;
     const int co1 = combo & 7, c0g = combo >> 3;
     // Cells are walked column-major, so the 4 cells a wave gathers at once share cx and differ in cy: their window
-    // offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks, and the second channel half (3 planes = 2370 floats
-    // = +2 banks) takes the other 16 -> the 9-tap gathers are conflict-free (row-major neighbours collided 2-3 way).
+    // offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks (bank mod 4 in {0,1}), and the second channel half (2 planes =
+    // 1582 floats = +14 banks: bank mod 4 in {2,3}) takes the other 16 -> the 9-tap gathers are conflict-free (row-major
+    // neighbours collided 2-3 way).
     for (int e = tid; e < PC; e += CNN_NT_BWD) {
         const int cy = e % PW, cx = e / PW;
         celloff[e] = (((2 * cy) * XP_RS + 2 * cx) << 8) | (cy * PW + cx);
@@ -341,7 +364,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
         const int loc = f.loc, pc = f.pc;
         if (!CNN_BWD_PREFETCH) fetch_acts(s);
-        cnn_stage<CIN, CNN_NT_BWD>(f, xp);
+        cnn_stage<XP_PLANE_B, CNN_NT_BWD>(f, xp);
         if (own) {
 #pragma unroll
             for (int co = 0; co < 4; ++co) {
@@ -353,8 +376,6 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
             for (int co = 0; co < C2; ++co)
                 dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
         }
-        __syncthreads();
-        cnn_set_onehots<CIN>(xp, loc, pc);
         if (s + gridDim.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
         __syncthreads();
         // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
@@ -406,25 +427,38 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
             const int tab = celloff[c], cid = tab & 255;
             const float gv = gbuf[co1 * PC + cid];
             const int am = ambuf[cid * C1 + co1];
-            const float* base = xp + (c0g * CG) * XP_PLANE + (tab >> 8) + (am >> 1) * XP_RS + (am & 1);
+            const float* base = xp + (c0g * CG) * XP_PLANE_B + (tab >> 8) + (am >> 1) * XP_RS + (am & 1);
 #pragma unroll
             for (int j = 0; j < CG; ++j)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
-                        aw1[j * 9 + ky * 3 + kx] = __builtin_fmaf(gv, base[j * XP_PLANE + ky * XP_RS + kx], aw1[j * 9 + ky * 3 + kx]);
+                        aw1[j * 9 + ky * 3 + kx] = __builtin_fmaf(gv, base[j * XP_PLANE_B + ky * XP_RS + kx], aw1[j * 9 + ky * 3 + kx]);
             aw1[AW - 1] += gv;
         }
 #endif
-        __syncthreads();
-        cnn_clear_onehots<CIN>(xp, loc, pc);
+        if (CIN == 6 && tid < 2 * C1 * 9) {
+            // one-hot input at (r, c): tap (ky, kx) of conv1 meets it at output pixel (r - ky + 1, c - kx + 1); that pixel carries
+            // gradient iff it is its pool window's arg-max for channel co
+            const int cell = st_which ? loc : pc;
+            if (cell >= 0) {
+                const int r = cell / MAPW, c = cell - r * MAPW;
+                const int y = r + st_dy, x = c + st_dx;
+                if (y >= 0 && y < 2 * PW && x >= 0 && x < 2 * PW) {
+                    const int pcell = (y >> 1) * PW + (x >> 1);
+                    if (ambuf[pcell * C1 + st_co] == (((y & 1) << 1) | (x & 1))) gst += gbuf[st_co * PC + pcell];
+                }
+            }
+        }
         __syncthreads();
     }
     // ---- workgroup reduction (fixed order) -> slab row
     __syncthreads();
-    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW] then [NWAVE][16][80]
+    float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW], [NWAVE][16][80], [2][8][9]
     float* red2 = red + CNN_NT_BWD * AW;
+    float* gred = red2 + NWAVE * 16 * 80;
+    if (tid < 2 * C1 * 9) gred[tid] = gst;
 #pragma unroll
     for (int k = 0; k < AW; ++k) red[tid * AW + k] = aw1[k];
 #pragma unroll
@@ -436,15 +470,22 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     float* out = slab + (size_t)blockIdx.x * ROW;
     for (int e = tid; e < C1 * K1 + C1; e += CNN_NT_BWD) {
         int o1, cb, slot;
+        float sum = 0.0f;
         if (e < C1 * K1) {
             o1 = e / K1;
-            const int k = e - o1 * K1, i0 = k / 9, kk = k - i0 * 9;
-            cb = o1 + 8 * (i0 / CG);
-            slot = (i0 % CG) * 9 + kk;
+            const int k = e - o1 * K1, i0 = k / 9, kk = k - i0 * 9;      // i0: the LOGICAL input channel (torch weight order)
+            constexpr int CH0 = (CIN == 6) ? 2 : 0;
+            if (i0 < CH0) {                                               // prediction (0) / location (1): the stamp gathers
+                out[e] = gred[(i0 * C1 + o1) * 9 + kk];
+                continue;
+            }
+            const int d = i0 - CH0;                                       // dense plane
+            cb = o1 + 8 * (d / CG);
+            slot = (d % CG) * 9 + kk;
+            if (CIN == 6 && d == 0) sum = -gred[(C1 + o1) * 9 + kk];      // others = combined - location
         } else {
             o1 = e - C1 * K1; cb = o1; slot = AW - 1;           // db1 lives on the first-half threads
         }
-        float sum = 0.0f;
 #pragma unroll
         for (int gi = 0; gi < NGRP; ++gi) sum += red[(gi * NCOMBO + cb) * AW + slot];
         out[e] = sum;
@@ -458,10 +499,10 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     }
 }
 
-inline size_t fwd_lds(int cin) { return sizeof(float) * (size_t)(cin * XP_PLANE + C1 * PP_PLANE); }
-inline size_t bwd_lds(int cin) {
-    size_t img = (size_t)(cin * XP_PLANE + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
-    size_t red = (size_t)(CNN_NT_BWD * ((cin / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80) * 4;
+inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(DP * XP_PLANE + C1 * PP_PLANE + 2 * 9 * C1); }
+inline size_t bwd_lds(int) {
+    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
+    size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
 // persistent grid: exactly as many workgroups as are resident at once (occupancy query x CU count), so no second,

@@ -100,7 +100,7 @@ def _pack(env_sets: Dict[str, tuple], runs: int, with_obstacles: bool, device):
 @torch.no_grad()
 def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montecarlo_runs: int = 100, steps_per_episode: int = 120,
                           obstruction_count: int = 0, enforce_grid_boundaries: bool = True, seed: int = 0,
-                          device: str = "cuda:0", return_actions: bool = False):
+                          device: str = "cuda:0", return_actions: bool = False, falloff: str = "reference"):
     """EpisodeRunner.run for every saved environment at once.  Returns (List[MonteCarloResults] in set order, summary
     dict with the statistics `evaluate.py:776-828` prints); with return_actions also the [steps, E*R] action log."""
     E, R, L = len(env_sets), montecarlo_runs, steps_per_episode
@@ -108,7 +108,7 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
     dev = torch.device(device)
     with_obs = obstruction_count != 0
     vec = RadSearchVec(N, number_agents=1, obstruction_count=obstruction_count, enforce_grid_boundaries=enforce_grid_boundaries,
-                       seed=seed, device=device)
+                       seed=seed, device=device, falloff=falloff)
     keys, src, det, inten, bkg, nob, rects = _pack(env_sets, R, with_obs, dev)
     vec.reset()                                                   # a valid handle state; every episode is then loaded
     obs = vec.refresh(src, det, inten, bkg, nob, rects)[0].clone()

@@ -183,6 +183,23 @@ def load_test_environments(path: str) -> Dict[str, tuple]:
     return result
 
 
+def sets_from_arrays(src, det, intensity, bkg, rects=None) -> Dict[str, tuple]:
+    """The reference's set structure from plain arrays (tests/golden/testset_obs<k>_<snr>.npz: the first 100 environments of a saved
+    set as written by tests/golden/make_checkpoints.py): src / det [E, 2], intensity / bkg [E], rects [E, k, 4, 2] corner lists."""
+    out = {}
+    for i in range(len(src)):
+        e = [np.asarray(src[i], dtype=np.float64), np.asarray(det[i], dtype=np.float64), int(intensity[i]), int(bkg[i])]
+        if rects is not None and np.asarray(rects).shape[1] > 0:
+            e.append([[np.asarray(r, dtype=np.float64)] for r in rects[i]])
+        out[f"env_{i}"] = tuple(e)
+    return out
+
+
+def load_test_environments_npz(path: str) -> Dict[str, tuple]:
+    z = np.load(path)
+    return sets_from_arrays(z["src"], z["det"], z["intensity"], z["bkg"], z["rects"])
+
+
 def summarize_test_set(env_sets: Dict[str, tuple]) -> Dict[str, Any]:
     """Counts and ranges of a set (what test_env_gen.py:38-60 classifies): signal-to-noise I / r^2 / bkg + 1 of the start."""
     src = np.array([e[0] for e in env_sets.values()], dtype=np.float64)

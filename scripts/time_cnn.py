@@ -7,7 +7,7 @@ lib = _lib.load()
 S, A = 32768, 4
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 maps = (torch.rand(S, 4, 27, 27, device="cuda", generator=g) * (torch.rand(S, 4, 27, 27, device="cuda", generator=g) < 0.15)).contiguous()
-cells = torch.randint(0, 729, (S, A), device="cuda", generator=g); pcells = torch.full((S, A), -1, device="cuda", dtype=torch.int64)
+cells = torch.randint(0, 729, (S, A), device="cuda", generator=g); pcells = torch.where(torch.rand(S, A, device="cuda", generator=g) < 0.9, torch.randint(0, 729, (S, A), device="cuda", generator=g), torch.full((S, A), -1, device="cuda", dtype=torch.int64))
 st = torch.cuda.current_stream().cuda_stream
 for cin, agent in ((6, 0), (4, -1)):
     w1 = torch.randn(8, cin, 3, 3, device="cuda") * 0.2; b1 = torch.rand(8, device="cuda") * 0.1
