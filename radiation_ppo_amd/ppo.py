@@ -153,7 +153,7 @@ class FusedPPOGrad:
         all-reduces of this size are latency bound: the count matters, not the bytes).  rs_adam_step then takes the
         statistics from the bucket.  The loss weights already carry 1/(global env count): SUM over ranks = the reference's
         average.  After the KL early stop rs_ppo_grad publishes zeros, so the remaining (no-op) iterations reduce zeros."""
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        Collectives.all_reduce_sum(self.bucket)
         self.stats_from_bucket = True
 
     def assign_grads(self) -> None:
@@ -306,6 +306,38 @@ def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class Collectives:
+    """Every data-path collective of the update loops goes through here: `count` is what the 2-rank tests read to hold the paths to
+    ONE all-reduce per optimiser step (at 42-355 KB an xGMI ring all-reduce is latency bound, so the number of
+    collectives matters, not their bytes)."""
+    count = 0
+
+    @staticmethod
+    def all_reduce_sum(t: torch.Tensor) -> None:
+        Collectives.count += 1
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def reduce_grads_and_stats(params, stats: torch.Tensor) -> torch.Tensor:
+    """mpi_avg_grads (mpi_pytorch.py:26-33) + mpi_avg of the loss statistics (ppo.py:1250) as ONE flattened all-reduce: the bucket is
+    every gradient followed by the float64 statistics as float32 (hi, lo) pairs (~1e-14 relative loss against a float64 sum), as the
+    MLP path's device bucket (FusedPPOGrad.allreduce).  The loss weights already carry 1 / (global env count): SUM = the reference's
+    average.  The gradients are written back in place; returns the reduced statistics (float64)."""
+    if _world() == 1:
+        return stats
+    ps = [p for p in params if p.grad is not None]
+    hi = stats.float()
+    lo = (stats - hi.double()).float()
+    flat = torch.cat([p.grad.reshape(-1) for p in ps] + [hi.reshape(-1), lo.reshape(-1)])
+    Collectives.all_reduce_sum(flat)
+    o = 0
+    for p in ps:
+        p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+        o += p.numel()
+    k = stats.numel()
+    return (flat[o:o + k].double() + flat[o + k:o + 2 * k].double()).view_as(stats)
+
+
 class VecAgentPPO:
     """One agent id's networks + optimiser; the vectorised counterpart of AgentPPO (ppo.py:505-1355)."""
 
@@ -340,19 +372,6 @@ class VecAgentPPO:
                 p.data.copy_(flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
 
-    def _allreduce_grads(self) -> None:
-        """mpi_avg_grads (mpi_pytorch.py:26-33) as ONE flattened all-reduce.  The loss weights already carry
-        1/(global env count), so the sum over ranks is the reference's average over ranks."""
-        if _world() == 1:
-            return
-        params = [p for p in self.agent.parameters() if p.grad is not None]
-        flat = torch.cat([p.grad.view(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        o = 0
-        for p in params:
-            p.grad.copy_(flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
-
     def update_agent(self, X: torch.Tensor, act: torch.Tensor, adv: torch.Tensor, ret: torch.Tensor,
                      logp_old: torch.Tensor, w: torch.Tensor) -> UpdateResult:
         """update_agent (ppo.py:746-813) + update_rada2c (:1150-1281) on the whole batch.  w sums to 1 over
@@ -375,15 +394,13 @@ class VecAgentPPO:
             with torch.no_grad():
                 clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
                 stats = torch.stack([(w * (logp_old - logp)).sum(), ent_m.detach(), (w * clipped.float()).sum(),
-                                     val_loss.detach(), loss.detach()])
-                if _world() > 1:
-                    dist.all_reduce(stats, op=dist.ReduceOp.SUM)       # mpi_avg(kl) (ppo.py:1250)
-                stats_h = stats.tolist()                               # the early-stop decision needs the host
+                                     val_loss.detach(), loss.detach()]).double()
+            self.pi_optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            # mpi_avg(kl) (ppo.py:1250) + mpi_avg_grads (:1256): one collective, the statistics behind the gradients
+            stats_h = reduce_grads_and_stats(self.agent.parameters(), stats).tolist()   # the early-stop decision needs the host
             last = stats_h
             if stats_h[0] < thr:
-                self.pi_optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                self._allreduce_grads()
                 self.pi_optimizer.step()
             else:
                 kl_reached = True
@@ -449,12 +466,12 @@ def normalize_advantages(adv: torch.Tensor) -> torch.Tensor:
     s = adv.double().sum().view(1)
     if _world() > 1:
         pack = torch.cat([s, n])
-        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+        Collectives.all_reduce_sum(pack)
         s, n = pack[0:1], pack[1:2]
     mean = (s / n).float()
     sq = ((adv - mean) ** 2).double().sum().view(1)
     if _world() > 1:
-        dist.all_reduce(sq, op=dist.ReduceOp.SUM)
+        Collectives.all_reduce_sum(sq)
     std = torch.sqrt(sq / n).float()
     return (adv - mean) / std
 

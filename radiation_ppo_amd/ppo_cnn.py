@@ -23,7 +23,7 @@ from . import _lib
 from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps
 from .pfgru import PredictorBank
-from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
+from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
 
 
 class ActorLoss(torch.autograd.Function):
@@ -72,18 +72,6 @@ class CNNAgentPPO:
         self.pi_scheduler = torch.optim.lr_scheduler.StepLR(self.pi_optimizer, step_size=100, gamma=0.99)
         self.critic_scheduler = torch.optim.lr_scheduler.StepLR(self.critic_optimizer, step_size=100, gamma=0.99)
         self.chunk = chunk
-
-    @staticmethod
-    def _allreduce(params) -> None:
-        if _world() == 1:
-            return
-        ps = [p for p in params if p.grad is not None]
-        flat = torch.cat([p.grad.view(-1) for p in ps])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        o = 0
-        for p in ps:
-            p.grad.copy_(flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
 
     def sync_params(self) -> None:
         if _world() > 1:
@@ -140,11 +128,12 @@ class CNNAgentPPO:
                     clipped = (ratio > 1 + self.clip_ratio) | (ratio < 1 - self.clip_ratio)
                     stats += torch.stack([(w[lo:hi] * (logp_old[lo:hi] - logp)).sum(), (w[lo:hi] * ent).sum(),
                                           (w[lo:hi] * clipped.float()).sum(), loss.detach()]).double()
-            if _world() > 1:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-            last = stats.tolist()
+            # ONE collective per actor iteration: the statistics (KL first) ride behind the gradients in the same bucket
+            # (mpi_avg_grads + mpi_avg, ppo.py:841 / :838).  The KL decision is taken on the host: an iteration here is four
+            # 524 288-sample chunks through K9 / K10 (tens of milliseconds), so the one read costs nothing and a stopped loop
+            # must not enqueue further passes.
+            last = reduce_grads_and_stats(self.pi.parameters(), stats).tolist()
             if last[0] < thr:                                                   # ppo.py:838-845
-                self._allreduce(self.pi.parameters())
                 self.pi_optimizer.step()
             else:
                 kl_reached = True
@@ -152,19 +141,19 @@ class CNNAgentPPO:
         self.pi_scheduler.step()
         loss_c = float("nan")
         if update_critic:                                                       # ppo.py:858-873
+            tot = None
             for _ in range(self.train_v_iters):
                 self.critic_optimizer.zero_grad(set_to_none=True)
-                tot = torch.zeros((), dtype=torch.float64, device=self.device)
+                tot = torch.zeros(1, dtype=torch.float64, device=self.device)
                 for lo in range(0, M, self.chunk):
                     hi = min(lo + self.chunk, M)
                     v = self._values(critic_in(lo, hi))
                     lc = (w[lo:hi] * (v - ret[lo:hi]) ** 2).sum()               # MSE (ppo.py:1040-1045)
                     lc.backward()
                     tot += lc.detach().double()
-                if _world() > 1:
-                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-                self._allreduce(self.critic.parameters())
+                tot = reduce_grads_and_stats(self.critic.parameters(), tot)     # one collective; no host round trip in this loop
                 self.critic_optimizer.step()
+            if tot is not None:
                 loss_c = float(tot.item())
             self.critic_scheduler.step()
         return UpdateResult(stop_iteration=kk, loss_policy=last[3], loss_critic=loss_c, loss_predictor=0.0, kl_divergence=last[0],

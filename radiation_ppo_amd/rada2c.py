@@ -41,7 +41,7 @@ import torch.nn.functional as F
 from . import _lib
 from .envs import RadSearchVec
 from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
-from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages
+from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
 
 
 class _SeqPt(nn.Module):
@@ -515,16 +515,6 @@ class RNNAgentPPO:
             for p in self.agent.parameters():
                 dist.broadcast(p.data, src=0)
 
-    def _allreduce(self, params) -> None:
-        if _world() == 1:
-            return
-        ps = [p for p in params if p.grad is not None]
-        flat = torch.cat([p.grad.view(-1) for p in ps])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        o = 0
-        for p in ps:
-            p.grad.copy_(flat[o:o + p.numel()].view_as(p)); o += p.numel()
-
     # ---- PFGRU over an episode chunk; returns loc [L, E, 2] and (optionally) per-particle predictions [L, E, P, 2]
     def _pfgru_pass(self, X3: torch.Tensor, draws, want_particles: bool):
         cell = self.agent.model
@@ -675,14 +665,12 @@ class RNNAgentPPO:
                 loss = self.model_loss(B, sl, d)
                 loss.backward()
                 tot += loss.detach().double()
-            if _world() > 1:
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            self._allreduce(cell.parameters())
+            tot = reduce_grads_and_stats(cell.parameters(), tot.view(1))           # one collective per PFGRU iteration
             torch.nn.utils.clip_grad_norm_(cell.parameters(), 5)                    # :1137 (after the average here, see header)
             self.model_optimizer.step()
-            last = float(tot.item())
+            last = tot
         cell.eval()
-        return last
+        return float(last.item()) if torch.is_tensor(last) else last             # one host read, after the loop
 
     def loc_prefetch(self, B: EpisodeBatch, it: int):
         """The no-grad PFGRU passes of policy iteration `it` (K11, every chunk) enqueued on a side stream: they depend on the batch and
@@ -777,11 +765,10 @@ class RNNAgentPPO:
             loss, st = self.a2c_losses(B, sl, d, loc=None if locs is None else locs[ci])
             loss.backward()
             stats += st
-        if _world() > 1:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)                            # mpi_avg(kl) (:1250)
-        s = stats.tolist()
+        # mpi_avg(kl) (:1250) and mpi_avg_grads (:1256) in ONE collective: the statistics ride behind the gradients; the KL decision
+        # is one host read per policy iteration (a stopped loop must not enqueue another pass over every episode)
+        s = reduce_grads_and_stats(self.agent.pi.parameters(), stats).tolist()
         if s[0] < 1.5 * self.target_kl:
-            self._allreduce(self.agent.pi.parameters())
             self.pi_optimizer.step()
             return s, False
         return s, True

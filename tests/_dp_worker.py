@@ -14,7 +14,7 @@ torch.cuda.set_device(0)
 if world > 1:
     dist.init_process_group(backend="gloo")
 from radiation_ppo_amd.envs import RadSearchVec                      # noqa: E402
-from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO        # noqa: E402
+from radiation_ppo_amd.ppo import Collectives, FusedCollector, VecAgentPPO        # noqa: E402
 
 if mode == "cnn":
     # BASELINE config 5 in miniature: multi-agent RAD-TEAM (CNN actors, global critic, obstacles) sharded over ranks
@@ -33,12 +33,15 @@ if mode == "cnn":
             ag.use_loss_kernel = False
     col = CNNCollector(env, agents, T, L, True)
     col.collect()
+    c0 = Collectives.count
     res = col.update()
     if rank == 0:
         flat = torch.cat([p.detach().reshape(-1) for ag in agents.values() for p in ag.pi.parameters()]
                          + [p.detach().reshape(-1) for p in gc.parameters()]).cpu()
+        # expected: per agent 2 (global advantage mean / std, mpi_statistics_scalar) + one per actor iteration; + one per critic iteration
         torch.save({"params": flat, "kl": res[0].kl_divergence, "loss": res[0].loss_policy, "stop": res[0].stop_iteration,
-                    "entropy": res[0].Entropy, "loss_critic": res[0].loss_critic}, out)
+                    "entropy": res[0].Entropy, "loss_critic": res[0].loss_critic, "collectives": Collectives.count - c0,
+                    "collectives_expected": sum(2 + res[i].stop_iteration for i in range(A)) + 3}, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -54,11 +57,14 @@ if mode == "rnn":
     agents[0].sync_params()
     col = RNNCollector(env, agents, T, L)
     col.collect()
+    c0 = Collectives.count
     res = col.update()[0]
     if rank == 0:
         flat = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()]).cpu()
+        # expected: 2 (advantage statistics) + one per PFGRU iteration (2) + one per policy iteration
         torch.save({"params": flat, "kl": res.kl_divergence, "loss": res.loss_policy, "stop": res.stop_iteration,
-                    "entropy": res.Entropy, "loss_critic": res.loss_critic, "loss_predictor": res.loss_predictor}, out)
+                    "entropy": res.Entropy, "loss_critic": res.loss_critic, "loss_predictor": res.loss_predictor,
+                    "collectives": Collectives.count - c0, "collectives_expected": 2 + 2 + res.stop_iteration}, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

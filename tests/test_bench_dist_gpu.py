@@ -105,6 +105,8 @@ def test_data_parallel_cnn_equals_single_process(tmp_path):
     assert a["stop"] == b["stop"]
     assert abs(a["kl"] - b["kl"]) < 1e-6 and abs(a["loss"] - b["loss"]) < 1e-5 and abs(a["loss_critic"] - b["loss_critic"]) < 1e-5
     assert torch.allclose(a["params"], b["params"], rtol=1e-4, atol=3e-5), float((a["params"] - b["params"]).abs().max())
+    # ONE collective per actor / critic iteration (gradients + KL + statistics in one bucket) beside the two advantage-statistics ones
+    assert a["collectives"] == 0 and b["collectives"] == b["collectives_expected"], (b["collectives"], b["collectives_expected"])
 
 
 def test_data_parallel_rada2c_equals_single_process(tmp_path):
@@ -128,3 +130,4 @@ def test_data_parallel_rada2c_equals_single_process(tmp_path):
     # everything must stay within a fraction of a step, most elements far closer
     d = (a["params"] - b["params"]).abs()
     assert float(d.max()) <= 2.5e-3 and float((d > 2e-5).float().mean()) < 0.05, (float(d.max()), float((d > 2e-5).float().mean()))
+    assert a["collectives"] == 0 and b["collectives"] == b["collectives_expected"], (b["collectives"], b["collectives_expected"])

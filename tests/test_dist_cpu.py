@@ -36,7 +36,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from radiation_ppo_amd.ppo import normalize_advantages
+    from radiation_ppo_amd.ppo import Collectives, normalize_advantages
     ag = _agent()
     if rank == 1:                       # de-synchronise on purpose: sync_params must repair it
         with torch.no_grad():
@@ -47,9 +47,10 @@ def _worker(rank, world, port, out):
     n = X.shape[0] // world
     sl = slice(rank * n, (rank + 1) * n)
     adv_n = normalize_advantages(adv[sl])
+    c0 = Collectives.count
     res = ag.update_agent(X[sl], act[sl], adv_n, ret[sl], logp_old[sl], w[sl])
     flat = torch.cat([p.data.view(-1) for p in ag.agent.parameters()])
-    out.put((rank, flat.numpy(), adv_n.numpy(), res.stop_iteration, res.kl_divergence))
+    out.put((rank, flat.numpy(), adv_n.numpy(), res.stop_iteration, res.kl_divergence, Collectives.count - c0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,6 +86,7 @@ def test_two_rank_update_equals_single_process():
     assert np.allclose(np.concatenate([res[0][2], res[1][2]]), adv_n.numpy(), rtol=1e-5, atol=1e-6)
     assert res[0][3] == res[1][3] == r1.stop_iteration
     assert abs(res[0][4] - r1.kl_divergence) < 1e-6
+    assert res[0][5] == res[1][5] == r1.stop_iteration     # ONE collective per policy iteration: KL + statistics ride in the gradient bucket
 
 
 # ---------------------------------------------------------------------------------------- RAD-A2C ('rnn') under data parallelism
@@ -114,9 +116,10 @@ def _rnn_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radiation_ppo_amd.ppo import Collectives
     ag, res = _rnn_update(rank * 4, rank * 4 + 4, 8, rank * 4)
     flat = torch.cat([p.data.view(-1) for p in ag.agent.parameters()])
-    out.put((rank, flat.numpy(), res.stop_iteration, res.kl_divergence, res.loss_predictor, res.loss_policy))
+    out.put((rank, flat.numpy(), res.stop_iteration, res.kl_divergence, res.loss_predictor, res.loss_policy, Collectives.count))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -145,3 +148,5 @@ def test_two_rank_recurrent_update_equals_single_process():
     assert res[0][2] == one.stop_iteration
     assert np.isclose(res[0][3], one.kl_divergence, rtol=1e-3, atol=1e-6) and np.isclose(res[0][4], one.loss_predictor, rtol=1e-4)
     assert np.isclose(res[0][5], one.loss_policy, rtol=1e-3, atol=1e-6)
+    # one collective per PFGRU iteration (2) and per policy iteration (mpi_avg_grads + mpi_avg in one bucket, ppo.py:1139-1141, :1250-1256)
+    assert res[0][6] == res[1][6] == 2 + one.stop_iteration, (res[0][6], one.stop_iteration)
