@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 1
+#define RS_ABI_VERSION 2
 #define RS_OBS_DIM 11      /* [measurement, x/scale, y/scale, 8 range sensors]  rad_search_env.py:589-593 */
 #define RS_NUM_ACTIONS 9   /* 0..7 directions, 8 idle                           rad_search_env.py:55-68  */
 #define RS_MAX_AGENTS 8
@@ -68,6 +68,10 @@ typedef struct rs_config {
     int32_t geom_group_size;         /* envs sharing one obstacle layout; 1 = reference-faithful       */
     uint32_t seed;                   /* Philox key word 0                                              */
     uint32_t env_id_base;            /* global id of local env 0 (Philox key word 1 = base + n)        */
+    int32_t coord_noise;             /* coord_noise (rad_search_env.py:365, :569-580): N(0, 5 cm) on the two coordinates of the
+                                        OBSERVATION (not of the state), a fresh pair per agent-step (Philox stream 96 + agent) */
+    int32_t debug_spawn;             /* DEBUG (:387-389, :782-785, :1043-1090): source (500, 500), detector (1000, 1000), no
+                                        minimum-distance / line-of-sight resampling, intensity 1e6, background 0             */
 } rs_config;
 
 /* optional per-agent info outputs of rs_step / rs_reset (any pointer may be NULL); all device, [N,A] */

@@ -72,6 +72,7 @@ _MASK = 0xFFFFFFFF
 STREAM_RESET = 0
 STREAM_STEP = 1           # + agent id
 STREAM_GEOM = 64          # obstacle layouts shared by a group of envs (geom_group_size > 1)
+STREAM_NOISE = 96         # + agent id: coordinate noise of the observation (coord_noise)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -170,6 +171,14 @@ class PhiloxDraws:
             return u53(o[0], o[1]), u53(o[2], o[3])
         return poisson_from_uniforms(lam, next_uv)
 
+    def normal2(self, scale, agent):
+        """np_random.normal(scale=scale, size=2) (:570-574): one Philox block of stream 96 + agent -> Box-Muller in float64."""
+        o = philox4x32_10(0, self.t, self.episode, STREAM_NOISE + agent, self.k0, self.k1)
+        u1 = 1.0 - u53(o[0], o[1])
+        u2 = u53(o[2], o[3])
+        rad = scale * math.sqrt(-2.0 * math.log(u1))
+        return rad * math.cos(6.283185307179586 * u2), rad * math.sin(6.283185307179586 * u2)
+
 
 class PhiloxGeomDraws:
     """Draws for an obstacle layout shared by a group of envs: key = (seed, first env id of the
@@ -249,6 +258,15 @@ class ReplayDraws:
         self.pos += 1
         assert kind == 1 and a0 == lam, ("poisson lam", a0, lam)
         return int(v)
+
+    def normal2(self, scale, agent):
+        out = []
+        for _ in range(2):
+            kind, a0, a1, v = self.rows[self.pos]
+            self.pos += 1
+            assert kind == 2 and a0 == 0.0 and a1 == scale, ("normal args", (kind, a0, a1), scale)
+            out.append(float(v))
+        return tuple(out)
 
 
 # --------------------------------------------------------------------------- exact geometry
@@ -472,7 +490,10 @@ class OracleAgent:
 
 class RadSearchOracle:
     def __init__(self, draws, number_agents=1, obstruction_count=0, enforce_grid_boundaries=False,
-                 bbox=(0, 0, 2700, 2700), observation_area=(200, 500), falloff="reference", layout_fn=None):
+                 bbox=(0, 0, 2700, 2700), observation_area=(200, 500), falloff="reference", layout_fn=None,
+                 coord_noise=False, DEBUG=False):
+        self.coord_noise = coord_noise  # :365, :569-580
+        self.DEBUG = DEBUG              # :387-389: hard-coded spawn
         self.layout_fn = layout_fn      # callable() -> rects for shared layouts (geom_group_size > 1)
         self.rng = draws
         self.number_agents = number_agents
@@ -590,10 +611,11 @@ class RadSearchOracle:
         self.last_lam[agent.id] = lam
         if not agent.sp_dist < math.inf:
             self.err |= ERR_NO_PATH
-        # observation (:577-593); coord_noise is not supported (always 0.0)
+        # observation (:569-593)
         s = 1 / float(self.sa_y1)
-        ox = (agent.det[0] + 0.0) * s
-        oy = (agent.det[1] + 0.0) * s
+        noise = self.rng.normal2(5, agent.id) if self.coord_noise else (0.0, 0.0)
+        ox = (agent.det[0] + noise[0]) * s
+        oy = (agent.det[1] + noise[1]) * s
         if self.num_obs > 0 or self.enforce_grid_boundaries:
             sensors = self._obstruction_sensors(agent)
         else:
@@ -633,6 +655,8 @@ class RadSearchOracle:
             agent.prev_det_dist = shortest_path_len(self.src[0], self.src[1], det[0], det[1], self.rects, self.dsrc)
         self.intensity = self.rng.integers(1000000, 10000000)     # :778 (1e6, 10e6)
         self.bkg_intensity = self.rng.integers(10, 51)            # :779
+        if self.DEBUG:                                            # :782-785
+            self.intensity, self.bkg_intensity = 1000000, 0
         # :788-791 "Environment is not valid, retrying!": a full nested reset with a new layout, after which the
         # outer call still runs its own step(None) -- k rejected layouts cost k extra idle measurements.
         if self.layout_fn is None and not layout_is_valid(self.rects):
@@ -746,7 +770,11 @@ class RadSearchOracle:
 
     def _sample_source_loc_pos(self):
         source = self._rand_point()
+        if self.DEBUG:                       # :1043-1044 (the draw above is still consumed)
+            source = (500, 500)
         detector = self._rand_point()
+        if self.DEBUG:                       # :1052-1053
+            detector = (1000, 1000)
         det_clear = False
         while not det_clear:
             resamp = False
@@ -758,7 +786,7 @@ class RadSearchOracle:
                 detector = self._rand_point()
             else:
                 det_clear = True
-        src_clear = False
+        src_clear = self.DEBUG               # :1087-1088: DEBUG skips the minimum-distance / line-of-sight resampling
         resamp = False
         inter = False
         num_retry = 0

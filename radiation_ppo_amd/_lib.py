@@ -27,6 +27,7 @@ class RsConfig(C.Structure):
         ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("obstruction_count", C.c_int32),
         ("enforce_grid_boundaries", C.c_int32), ("bbox", C.c_int32 * 4), ("observation_area", C.c_int32 * 2),
         ("falloff", C.c_int32), ("geom_group_size", C.c_int32), ("seed", C.c_uint32), ("env_id_base", C.c_uint32),
+        ("coord_noise", C.c_int32), ("debug_spawn", C.c_int32),
     ]
 
 
@@ -156,7 +157,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rs_abi_version() != 1:
+    if lib.rs_abi_version() != 2:
         raise RuntimeError("librs_hip.so ABI version mismatch")
     _lib = lib
     return lib

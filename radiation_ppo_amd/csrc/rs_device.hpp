@@ -38,6 +38,7 @@
 #define RS_STREAM_STEP 1u      // + agent id
 #define RS_STREAM_ACT 32u      // + agent id
 #define RS_STREAM_GEOM 64u
+#define RS_STREAM_NOISE 96u    // + agent id: the coordinate noise of the observation
 
 // ---------------------------------------------------------------------------------------------
 // Kernel parameter block (passed by value as kernarg).  All arrays are SoA, env index fastest, so a
@@ -45,6 +46,7 @@
 struct RsParams {
     int N, A, G;                       // envs, agents, geometry groups (G = ceil(N / group))
     int obstruction_count, enforce, falloff, group;
+    int coord_noise, debug;            // coord_noise (:365, :569-580); DEBUG hard-coded spawn (:387-389, :782-785, :1043-1090)
     int uniform_nobs;                  // > 0: every env holds exactly this many rectangles (fixed obstruction_count and no
                                        // saved layout loaded by rs_refresh yet) -> obstacle loops are wave-uniform
     int bx0, by0, bx1, by1;            // bbox
@@ -100,6 +102,20 @@ struct RsDrawSeq {
         return lo + (int)__umul64hi(x, (uint64_t)(uint32_t)(hi - lo));
     }
 };
+
+// np_random.normal(scale=5, size=2) (rad_search_env.py:570-574): one Philox block -> two 53-bit uniforms -> Box-Muller in float64.
+// A real call (not inlined), like the rare Poisson branches below: the float64 log / sincos library code stays out of the register
+// budget of the env kernels, which only reach it with coord_noise set.
+struct RsNoise2 { double x, y; };
+__device__ __noinline__ RsNoise2 rs_coord_noise(uint32_t t, uint32_t episode, uint32_t agent, uint32_t k0, uint32_t k1) {
+    const u32x4 o = philox4x32_10(0u, t, episode, RS_STREAM_NOISE + agent, k0, k1);
+    const double u1 = 1.0 - u53(o.x, o.y);               // (0, 1]
+    const double u2 = u53(o.z, o.w);
+    const double rad = 5.0 * sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586 * u2, &sn, &cs);
+    return RsNoise2{rad * cs, rad * sn};
+}
 
 // The rare branches of the sampler are real function calls (not inlined): their float64 library code (exp, log, lgamma)
 // and constants otherwise sit in the register budget of EVERY env kernel -- the obstacle step kernel spilled 64-bit
@@ -676,8 +692,10 @@ __device__ __forceinline__ void rs_env_step_lane(const RsParams& P, const RsGeo&
         // ---- observation :570-593
         float* row = O.obs_row + a * RS_OBS_DIM;
         row[0] = (float)(double)meas;
-        row[1] = (float)(((double)x + 0.0) * P.scale);
-        row[2] = (float)(((double)y + 0.0) * P.scale);
+        double nx = 0.0, ny = 0.0;
+        if (P.coord_noise) { const RsNoise2 nz = rs_coord_noise(t, episode, (uint32_t)a, k0, k1); nx = nz.x; ny = nz.y; }
+        row[1] = (float)(((double)x + nx) * P.scale);
+        row[2] = (float)(((double)y + ny) * P.scale);
         RS_ESTAMP(5);                                        // reward, observation head
         if ((HAS_OBS && g.n > 0) || P.enforce) rs_sensors<HAS_OBS, CN>(P, g, px, py, row + 3, err, cj);
         else {
@@ -893,7 +911,9 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     }
     // ---- sample_source_loc_pos (:1013-1131); rand_point uses the x-range for both axes (:1033)
     srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1);
+    if (P.debug) { srx = 500; sry = 500; }              // DEBUG_SOURCE_LOCATION: the draws above are still consumed (:1040-1044)
     dtx = seq.integers(P.sa_x0, P.sa_x1); dty = seq.integers(P.sa_x0, P.sa_x1);
+    if (P.debug) { dtx = 1000; dty = 1000; }            // DEBUG_DETECTOR_LOCATION (:1050-1053)
     for (;;) {
         bool inside = false;
         for (int o = 0; o < g.n && !inside; ++o) {
@@ -904,7 +924,7 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
         dtx = seq.integers(P.sa_x0, P.sa_x1); dty = seq.integers(P.sa_x0, P.sa_x1);
     }
     int num_retry = 0;
-    for (;;) {
+    for (; !P.debug;) {                                 // DEBUG: no minimum-distance / line-of-sight resampling (:1087-1088)
         while (rs_dist_i(dtx, dty, srx, sry) < 1000.0) { srx = seq.integers(P.sa_x0, P.sa_x1); sry = seq.integers(P.sa_x0, P.sa_x1); }
         bool resamp = false, inter = false;
         for (int o = 0; o < g.n && !resamp; ++o) {
@@ -918,6 +938,7 @@ __device__ __forceinline__ void rs_env_reset_lane(const RsParams& P, RsGeo& g, i
     }
     intensity = seq.integers(1000000, 10000000);    // :778
     bkg = seq.integers(10, 51);                     // :779
+    if (P.debug) { intensity = 1000000; bkg = 0; }  // :782-785
     if (!resample || rs_layout_valid(lds_geo, RS_WAVE, lane, g.n)) break;
     extra_idle += 1;
     }

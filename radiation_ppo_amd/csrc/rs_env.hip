@@ -342,6 +342,7 @@ static size_t carve(const rs_config* c, unsigned char* base, rs_handle* h) {
         P.obstruction_count = c->obstruction_count; P.enforce = c->enforce_grid_boundaries ? 1 : 0;
         P.uniform_nobs = c->obstruction_count > 0 ? c->obstruction_count : 0;
         P.falloff = c->falloff ? 1 : 0; P.group = c->geom_group_size;
+        P.coord_noise = c->coord_noise ? 1 : 0; P.debug = c->debug_spawn ? 1 : 0;
         P.bx0 = c->bbox[0]; P.by0 = c->bbox[1]; P.bx1 = c->bbox[2]; P.by1 = c->bbox[3];
         P.oa_lo = c->observation_area[0]; P.oa_hi = c->observation_area[1];
         P.sa_x0 = P.bx0 + P.oa_lo; P.sa_y0 = P.by0 + P.oa_lo;       // rad_search_env.py:393-420

@@ -42,7 +42,8 @@ class RadSearchVec:
                  enforce_grid_boundaries: bool = False,
                  bbox=((0.0, 0.0), (2700.0, 0.0), (2700.0, 2700.0), (0.0, 2700.0)),
                  observation_area=(200.0, 500.0), seed: int = 0, env_id_base: int = 0,
-                 falloff: str = "reference", geom_group_size: int = 1, device: Union[str, torch.device] = "cuda:0"):
+                 falloff: str = "reference", geom_group_size: int = 1, device: Union[str, torch.device] = "cuda:0",
+                 coord_noise: bool = False, DEBUG: bool = False):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -58,7 +59,8 @@ class RadSearchVec:
             bbox=(min(xs), min(ys), max(xs), max(ys)),
             observation_area=(int(observation_area[0]), int(observation_area[1])),
             falloff=0 if falloff == "reference" else 1, geom_group_size=int(geom_group_size),
-            seed=int(seed) & 0xFFFFFFFF, env_id_base=int(env_id_base) & 0xFFFFFFFF)
+            seed=int(seed) & 0xFFFFFFFF, env_id_base=int(env_id_base) & 0xFFFFFFFF,
+            coord_noise=int(bool(coord_noise)), debug_spawn=int(bool(DEBUG)))
         nbytes = self.lib.rs_state_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("invalid RadSearch configuration")
@@ -228,9 +230,7 @@ class RadSearch:
                  observation_area=(200.0, 500.0), np_random: Optional[np.random.Generator] = None,
                  obstruction_count: int = 0, enforce_grid_boundaries: bool = False, save_gif: bool = False,
                  number_agents: int = 1, DEBUG: bool = False, seed: Optional[int] = None,
-                 device: Union[str, torch.device] = "cuda:0", **unused: Any):
-        if DEBUG:
-            raise NotImplementedError("DEBUG hard-coded spawn (rad_search_env.py:782-785) is out of scope")
+                 device: Union[str, torch.device] = "cuda:0", coord_noise: bool = False, **unused: Any):
         if seed is None:
             rng = np_random if np_random is not None else np.random.default_rng(0)
             seed = int(rng.integers(0, 2 ** 32))
@@ -254,10 +254,11 @@ class RadSearch:
         self.action_space = SimpleNamespace(n=A_SIZE)
         self.background_radiation_bounds = (10, 51)
         self.radiation_intensity_bounds = (1e6, 10e6)
-        self.coord_noise = False
+        self.coord_noise = bool(coord_noise)                    # rad_search_env.py:365
+        self.DEBUG = bool(DEBUG)                                # :387-389
         self.epoch_cnt = 0
         self._vec = RadSearchVec(1, number_agents, obstruction_count, enforce_grid_boundaries, bbox, observation_area,
-                                 seed=seed, device=device)
+                                 seed=seed, device=device, coord_noise=coord_noise, DEBUG=DEBUG)
         self.epoch_end = True
         self.reset()
 

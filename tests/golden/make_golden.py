@@ -301,6 +301,54 @@ def gen_env_callforms():
             np.savez_compressed(path, **d)
 
 
+def gen_env_options():
+    """coord_noise=True (rad_search_env.py:365, :569-580: N(0, 5) on the observation's coordinates, drawn per agent-step AFTER the
+    measurement) and DEBUG=True (:387-389, :782-785, :1043-1090: hard-coded source / detector / intensities, no spawn resampling),
+    both from the reference itself with every draw recorded.  Same row format as env_*.npz; meta = [seed, A, enforce, noise, debug]."""
+    from gym_rad_search.envs.rad_search_env import RadSearch
+    for name, A, kw in (("envopt_noise_a1", 1, dict(coord_noise=True)), ("envopt_noise_a2", 2, dict(coord_noise=True)),
+                        ("envopt_debug_a1", 1, dict(DEBUG=True))):
+        rec = RecordingGenerator(97 + A)
+        env = RadSearch(number_agents=A, np_random=rec, obstruction_count=0, enforce_grid_boundaries=True, **kw)
+        rows = []
+        script = np.random.default_rng(600 + A)
+
+        def record(kind, actions, ret, log_start):
+            obs, rew, done, info = ret
+            rows.append(dict(
+                kind=kind, actions=actions,
+                obs=[np.asarray(obs[i], dtype=np.float64).tolist() for i in range(A)],
+                reward=[float(rew["individual_reward"][i]) for i in range(A)],
+                team=float("nan") if rew["team_reward"] is None else float(rew["team_reward"]),
+                done_ret=[bool(done[i]) for i in range(A)],
+                info_oob=[bool(info[i]["out_of_bounds"]) for i in range(A)],
+                info_oobc=[int(info[i]["out_of_bounds_count"]) for i in range(A)],
+                info_blocked=[bool(info[i]["blocked"]) for i in range(A)],
+                src=[float(env.src_coords[0]), float(env.src_coords[1])],
+                intensity=int(env.intensity), bkg=int(env.bkg_intensity),
+                draws=rec.log[log_start:], **_snapshot(env, A)))
+
+        ls = len(rec.log)
+        env.epoch_end = True
+        record("reset", [8] * A, env.reset(), ls)
+        steps_in_ep = 0
+        for t in range(90):
+            acts = [_greedy_action(env, i) if (t // 15) % 2 else int(script.integers(0, 9)) for i in range(A)]
+            ls = len(rec.log)
+            ret = env.step({i: acts[i] for i in range(A)})
+            record("step", acts, ret, ls)
+            steps_in_ep += 1
+            if env.done or steps_in_ep == 25:
+                ls = len(rec.log)
+                record("reset", [8] * A, env.reset(), ls)
+                steps_in_ep = 0
+        path = os.path.join(OUT, name + ".npz")
+        _save_env_rows(path, rows, A, dict(seed=97 + A, A=A, enforce=1))
+        d = dict(np.load(path).items())
+        d["meta"] = np.array([97 + A, A, 1, int(bool(kw.get("coord_noise"))), int(bool(kw.get("DEBUG")))], dtype=np.int64)
+        np.savez_compressed(path, **d)
+
+
 def _save_env_rows(path, rows, A, meta):
     n = len(rows)
     f8 = lambda k: np.array([r[k] for r in rows], dtype=np.float64)
@@ -1008,11 +1056,13 @@ if __name__ == "__main__":
     _install_placeholders()
     sys.path.insert(0, os.path.join(REF, "gym_rad_search"))
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["env", "envforms", "gae", "ff", "welford", "round2", "maps", "cnn", "pfgru", "train", "loss", "cnnloss", "refresh", "rada2c"]
+    which = sys.argv[1:] or ["env", "envforms", "envopt", "gae", "ff", "welford", "round2", "maps", "cnn", "pfgru", "train", "loss", "cnnloss", "refresh", "rada2c"]
     if "env" in which:
         gen_env_scenarios()
     if "envforms" in which:
         gen_env_callforms()
+    if "envopt" in which:
+        gen_env_options()
     if "gae" in which:
         gen_gae()
     if "ff" in which:

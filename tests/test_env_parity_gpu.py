@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 SEED = 289714752   # robust_seed(2) of the reference (main.py:478)
 
 
-def _make(N, A, obst, enforce, group=1, base=0, falloff="reference"):
+def _make(N, A, obst, enforce, group=1, base=0, falloff="reference", **opts):
     from radiation_ppo_amd.envs import RadSearchVec
     vec = RadSearchVec(N, number_agents=A, obstruction_count=obst, enforce_grid_boundaries=enforce, seed=SEED,
-                       env_id_base=base, geom_group_size=group, falloff=falloff)
+                       env_id_base=base, geom_group_size=group, falloff=falloff, **opts)
     oracles = []
     geom = {}
     for n in range(N):
@@ -40,6 +40,9 @@ def _make(N, A, obst, enforce, group=1, base=0, falloff="reference"):
     return vec, oracles, geom
 
 
+NOISY = False     # coord_noise: the two noisy coordinates pass through log / sincos of different float64 libraries (see the test)
+
+
 def _compare(vec, outs, refs, rets, tag):
     obs, rew, team, done = (t.cpu().numpy() for t in outs[:4])
     info = outs[4]
@@ -57,7 +60,11 @@ def _compare(vec, outs, refs, rets, tag):
         o, r, d, i = ret
         for a in range(env.number_agents):
             exp = np.asarray(o[a], dtype=np.float64).astype(np.float32)
-            assert np.array_equal(obs[n, a], exp), (tag, n, a, obs[n, a], exp)
+            if NOISY:
+                assert np.array_equal(np.delete(obs[n, a], [1, 2]), np.delete(exp, [1, 2])), (tag, n, a, obs[n, a], exp)
+                assert np.allclose(obs[n, a, 1:3], exp[1:3], rtol=0, atol=1e-9), (tag, n, a, obs[n, a, 1:3], exp[1:3])
+            else:
+                assert np.array_equal(obs[n, a], exp), (tag, n, a, obs[n, a], exp)
             assert rew[n, a] == np.float32(r["individual_reward"][a]), (tag, n, a, rew[n, a], r["individual_reward"][a])
             assert bool(done[n, a]) == bool(d[a]), (tag, n, a)
             assert bool(oob[n, a]) == i[a]["out_of_bounds"] and int(oobc[n, a]) == i[a]["out_of_bounds_count"], (tag, n, a)
@@ -69,10 +76,10 @@ def _compare(vec, outs, refs, rets, tag):
         assert team[n] == np.float32(r["team_reward"]), (tag, n)
 
 
-def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="reference", seed=0):
-    vec, specs, geom = _make(N, A, obst, enforce, group, base, falloff)
+def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="reference", seed=0, **opts):
+    vec, specs, geom = _make(N, A, obst, enforce, group, base, falloff, **opts)
     refs = [RadSearchOracle(PhiloxDraws(SEED, base + n), number_agents=A, obstruction_count=obst,
-                            enforce_grid_boundaries=enforce, falloff=falloff, layout_fn=fn) for n, fn in specs]
+                            enforce_grid_boundaries=enforce, falloff=falloff, layout_fn=fn, **opts) for n, fn in specs]
     outs = vec.reset()
     torch.cuda.synchronize()
     _compare(vec, outs, refs, [e._ret for e in refs], "reset0")
@@ -108,6 +115,47 @@ def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="refere
 
 def test_obstacle_free_single_agent_enforced():
     _run(N=200, A=1, obst=0, enforce=True, steps=70)
+
+
+@pytest.mark.parametrize("A,obst", [(1, 0), (3, 2)])
+def test_debug_spawn(A, obst):
+    """DEBUG=True (rad_search_env.py:387-389, :782-785, :1043-1090; the oracle's restatement is pinned to the reference by
+    tests/golden/envopt_debug_a1.npz): source (500, 500), detector (1000, 1000) unless it falls into a rectangle, no spawn resampling,
+    intensity 1e6, background 0 -- bit-exact like every other env output."""
+    refs = _run(N=64, A=A, obst=obst, enforce=True, steps=40, seed=5, DEBUG=True)
+    assert all(e.src == (500, 500) and e.intensity == 1000000 and e.bkg_intensity == 0 for e in refs)
+
+
+@pytest.mark.parametrize("A", [1, 2])
+def test_coord_noise(A):
+    """coord_noise=True (rad_search_env.py:365, :569-580; oracle pinned by tests/golden/envopt_noise_a*.npz): N(0, 5 cm) on the
+    observation's two coordinates, nothing else.  Kernel and oracle draw the same Philox block and apply the same Box-Muller formula
+    in float64, but through different log / sincos libraries (device ocml vs the host libm): the two float32 coordinates are held to
+    1e-9 (scaled units; a last-bit difference of the float64 noise moves them by ~1e-19), everything else bit-exact.  The noise as a
+    DISTRIBUTION (like the Poisson sampler): mean 0, standard deviation 5 cm, uncorrelated axes, normal (Kolmogorov-Smirnov)."""
+    global NOISY
+    NOISY = True
+    try:
+        _run(N=96, A=A, obst=0, enforce=True, steps=40, seed=7, coord_noise=True)
+    finally:
+        NOISY = False
+    from scipy import stats
+    from radiation_ppo_amd.envs import RadSearchVec
+    N = 1 << 16
+    vec = RadSearchVec(N, number_agents=A, obstruction_count=0, enforce_grid_boundaries=True, seed=11, coord_noise=True)
+    vec.reset()
+    idle = torch.full((N, A), 8, dtype=torch.int8, device="cuda")
+    zs = []
+    for _ in range(4):
+        obs = vec.step(idle)[0]
+        x = torch.stack([vec.state("x").T.double(), vec.state("y").T.double()], dim=-1)          # [N, A, 2] true lattice coordinates
+        zs.append(((obs[..., 1:3].double() * 2200.0 - x) / 5.0).cpu().numpy().reshape(-1, 2))
+    z = np.concatenate(zs)
+    n = z.shape[0]
+    assert abs(z.mean(axis=0)).max() < 5.0 / np.sqrt(n) and abs(z.std(axis=0) - 1.0).max() < 5.0 / np.sqrt(2 * n) + 2e-4
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 5.0 / np.sqrt(n)
+    assert stats.kstest(z[:200000, 0], "norm").pvalue > 1e-4 and stats.kstest(z[:200000, 1], "norm").pvalue > 1e-4
+    assert abs(np.corrcoef(z[:-A, 0], z[A:, 0])[0, 1]) < 5.0 / np.sqrt(n)             # consecutive (env, agent) streams are independent
 
 
 def test_obstacle_free_single_agent_unenforced():

@@ -20,19 +20,21 @@ def test_action_table(golden_dir):
 
 
 FORM_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "envforms_*.npz")))
+OPT_FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "envopt_*.npz")))
 
 
-@pytest.mark.parametrize("path", FILES + FORM_FILES, ids=[os.path.basename(f)[:-4] for f in FILES + FORM_FILES])
+@pytest.mark.parametrize("path", FILES + FORM_FILES + OPT_FILES, ids=[os.path.basename(f)[:-4] for f in FILES + FORM_FILES + OPT_FILES])
 def test_env_transitions_exact(path):
     """env_*: dict actions (and the single-int form for one agent).  envforms_*: step(int) for SEVERAL agents (same
     action for all, no collision rule) and step(None) mid-episode (rad_search_env.py:616-627, :676-690)."""
     g = dict(np.load(path).items())
     form = g.get("form")
-    seed, A, enforce = (int(v) for v in g["meta"])
+    seed, A, enforce = (int(v) for v in g["meta"][:3])
+    noise, debug = (bool(v) for v in g["meta"][3:5]) if len(g["meta"]) >= 5 else (False, False)      # envopt_*: coord_noise / DEBUG
     draws = ReplayDraws([(int(k), a0, a1, v) for (_, k, a0, a1, v) in g["draws"]])
     n_events = len(g["is_reset"])
     # the fixture's first event is a reset with epoch_end=True: the constructor's reset plays it
-    env = RadSearchOracle(draws, number_agents=A, obstruction_count=0, enforce_grid_boundaries=bool(enforce))
+    env = RadSearchOracle(draws, number_agents=A, obstruction_count=0, enforce_grid_boundaries=bool(enforce), coord_noise=noise, DEBUG=debug)
     ret = env._ret
     steps_in_ep = 0
     for e in range(n_events):
