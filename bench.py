@@ -62,24 +62,46 @@ def cnn_trunk_flops(cin: int, backward: bool) -> float:
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _py_worker(args):
-    wid, n_envs, seconds = args
+    wid, n_envs, seconds = args[:3]
+    obst, agents = (args[3], args[4]) if len(args) > 3 else (0, 1)
     import random
     from oracle.radsearch_oracle import PhiloxDraws, RadSearchOracle
-    envs = [RadSearchOracle(PhiloxDraws(SEED, wid * n_envs + i), number_agents=1, obstruction_count=0,
+    envs = [RadSearchOracle(PhiloxDraws(SEED, wid * n_envs + i), number_agents=agents, obstruction_count=obst,
                             enforce_grid_boundaries=True) for i in range(n_envs)]
     rnd = random.Random(wid)
     steps = 0
     t_in = [0] * n_envs
+    t_epoch = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
+        t_epoch += 1
         for i, e in enumerate(envs):
-            e.step({0: rnd.randrange(9)})
+            e.step({a: rnd.randrange(9) for a in range(agents)})
             t_in[i] += 1
             steps += 1
-            if e.done or t_in[i] == L_EPISODE:
+            if e.done or t_in[i] == L_EPISODE or t_epoch == T_EPOCH:
+                if t_epoch == T_EPOCH:
+                    e.epoch_end = True                     # a new obstacle layout per 480-step epoch (train.py:482-484)
                 e.reset()
                 t_in[i] = 0
+        if t_epoch == T_EPOCH:
+            t_epoch = 0
     return steps, time.perf_counter() - t0
+
+
+def cpu_baseline_obstacles(obst: int, agents: int, seconds: float = 5.0):
+    """The configuration's own CPU figure: the Python oracle (the port closest to the reference's Python env.step; obstacle geometry
+    = the exact-lattice restatement of the visilibity calls) on the host cores, the config's obstruction_count and agent count, uniform
+    random actions, a fresh layout every 480 steps.  (oracle/radsearch_oracle.c restates the obstacle-free env only.)"""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_py_worker, [(w, 8, seconds, obst, agents) for w in range(cores)])
+    one = res[0]
+    return {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env steps/s", "cores": cores, "kind": "port",
+            "single_core_value": one[0] / one[1],
+            "sample": f"{cores} procs x 8 envs, obstruction_count={obst}, {agents} agent(s), uniform random actions, ~{seconds:.0f} s each, "
+                      "oracle/radsearch_oracle.py (pure Python); env step + reset only, no policy"}
 
 
 def _c_lib():
@@ -245,7 +267,7 @@ def pmc_traffic():
 
 
 # ------------------------------------------------------------------------------------------------ configs 3 and 4
-def run_config3(dev, iters: int = 2, warmup: int = 1):
+def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     """BASELINE config 3: single agent, 1 source + random obstructions (U{1..5} rectangles per env, resampled every
     epoch), 8192 envs, 2x64 MLP -- the same PPO iteration as the headline."""
     import torch
@@ -305,10 +327,12 @@ def run_config3(dev, iters: int = 2, warmup: int = 1):
     out["env_error_flags"] = flags
     del col, env, ag
     torch.cuda.empty_cache()
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_obstacles(-1, 1)
     return out
 
 
-def run_config4(dev, iters: int = 1, warmup: int = 1):
+def run_config4(dev, iters: int = 1, warmup: int = 1, cpu: bool = True):
     """BASELINE config 4: multi-agent RAD-TEAM, 4 agents, CNN actors + global critic on the heat maps, random
     obstructions, 4096 envs."""
     import torch
@@ -360,17 +384,19 @@ def run_config4(dev, iters: int = 1, warmup: int = 1):
     out["env_error_flags"] = env.error_flags()
     del col, env, ag, gc, gco
     torch.cuda.empty_cache()
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_obstacles(-1, A)
     return out
 
 
-def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
+def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     """SURVEY section 8 row f2 (not a BASELINE config): the reference's original single-agent RAD-A2C -- GRU actor-critic + PFGRU
     location predictor, 15 PFGRU + <= 40 policy iterations over whole episodes per epoch."""
     import torch
     from radiation_ppo_amd import _lib
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
-    N, T, L = 1024, T_EPOCH, L_EPISODE
+    N, T, L = int(os.environ.get("RS_A2C_ENVS", ENVS_PER_GPU)), T_EPOCH, L_EPISODE     # the metric's size: 4096 envs
     torch.manual_seed(SEED % (2 ** 31))
     torch.cuda.reset_peak_memory_stats(dev)
     env = RadSearchVec(N, number_agents=1, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED, device=dev)
@@ -391,7 +417,7 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1):
     dt = time.perf_counter() - t0
     ev, _lib.EVENTS = _lib.EVENTS, None
     out = {"workload": "single-agent RAD-A2C (GRU(13->24) actor-critic + PFGRU predictor, 40 particles), U{1..5} random rectangles, "
-                       "1024 envs, 480 steps/epoch; step = 1 PPO iteration (rollout + 15 PFGRU iterations (K13) + <=40 policy iterations "
+                       f"{N} envs, 480 steps/epoch; step = 1 PPO iteration (rollout + 15 PFGRU iterations (K13) + <=40 policy iterations "
                        "through K11 / K12)",
            "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
@@ -586,7 +612,7 @@ def main():
             for c in [x.strip() for x in which.split(",") if x.strip() and x.strip() != "none"]:
                 key = "row_f2_rada2c" if c == "a2c" else f"config{c}"
                 try:
-                    extra[key] = {"3": run_config3, "4": run_config4, "a2c": run_config_a2c}[c](dev)
+                    extra[key] = {"3": run_config3, "4": run_config4, "a2c": run_config_a2c}[c](dev, cpu=not args.no_cpu_baseline)
                 except Exception as e:  # noqa: BLE001
                     extra[key] = {"error": repr(e)}
             if extra:

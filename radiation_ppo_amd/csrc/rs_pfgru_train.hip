@@ -315,11 +315,12 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) accH0[i][j] = f4{0, 0, 0, 0};
-    float aw2[2][ROW], awo[28];
+    // the two thin gradients (hid_obs[2]: 2 x 25, fc_obs: 28) ride on the matrix cores as well: row 0 (rows 0, 1) of one more
+    // 16-row tile each.  As per-lane FMA accumulators they were 78 registers of a kernel that already holds 512: the compiler spilled
+    // exactly that much (316 B of scratch per lane, written and re-read every step: +75 % HBM write traffic in the PMC pass)
+    f4 accW2[1][2], accO[1][2];
 #pragma unroll
-    for (int k = 0; k < ROW; ++k) { aw2[0][k] = 0.0f; aw2[1][k] = 0.0f; }
-#pragma unroll
-    for (int k = 0; k < 28; ++k) awo[k] = 0.0f;
+    for (int j = 0; j < 2; ++j) { accW2[0][j] = f4{0, 0, 0, 0}; accO[0][j] = f4{0, 0, 0, 0}; }
     float dh[H], dp = 0.0f;
 #pragma unroll
     for (int u = 0; u < H; ++u) dh[u] = 0.0f;
@@ -413,12 +414,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         // ---- hid_obs backwards: thin gradients in per-lane accumulators, hid_obs[0]'s on the matrix cores
         float du[H];
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            aw2[0][k] = fmaf(dop[0], uu[k], aw2[0][k]);
-            aw2[1][k] = fmaf(dop[1], uu[k], aw2[1][k]);
-            du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
-        }
-        aw2[0][H] += dop[0]; aw2[1][H] += dop[1];
+        for (int k = 0; k < H; ++k) du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
         float dv[H];
 #pragma unroll
         for (int o = 0; o < H; ++o) dv[o] = 0.0f;
@@ -430,6 +426,16 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         }
         __builtin_amdgcn_wave_barrier();
         outer_acc<2, 2>(DT, IT, accH0, lane);
+        __builtin_amdgcn_wave_barrier();
+        // d hid_obs[2] = sum over particles (and the mean) of dop (x) [relu(u) | 1]: rows 0, 1 of a tile (rows 2..15 hold stale du: their
+        // products land in accumulator rows that are never stored)
+        if (stage) {
+            DT[0 * SP + lane] = act41 ? dop[0] : 0.0f; DT[1 * SP + lane] = act41 ? dop[1] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act41 ? uu[k] : 0.0f;      // row 24 still holds the ones
+        }
+        __builtin_amdgcn_wave_barrier();
+        outer_acc<1, 2>(DT, IT, accW2, lane);
         __builtin_amdgcn_wave_barrier();
         // ---- gradient at the resampled particles and their log weights
         float dot = 0.0f;
@@ -463,15 +469,20 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         const float dlp = dp1 - expf(p1) * wave_sum(dp1);            // through p1 = lp - logsumexp(lp); also d / d p0
         dp = dlp;
-        // ---- fc_obs
+        // ---- fc_obs: d fc_obs = sum over particles of dlp (x) [h1 | x | 1] (row 0 of a tile, as d hid_obs[2] above)
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            awo[k] = fmaf(dlp, h1[k], awo[k]);
-            dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
+        for (int k = 0; k < H; ++k) dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
+        if (stage) {
+            DT[0 * SP + lane] = act ? dlp : 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? h1[k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = act ? x[k] : 0.0f;
+            IT[27 * SP + lane] = act ? 1.0f : 0.0f;
         }
-#pragma unroll
-        for (int k = 0; k < IN; ++k) awo[H + k] = fmaf(dlp, x[k], awo[H + k]);
-        awo[27] += dlp;
+        __builtin_amdgcn_wave_barrier();
+        outer_acc<1, 2>(DT, IT, accO, lane);
+        __builtin_amdgcn_wave_barrier();
         // ---- h1 = (1 - z) n + z h0, n = tanh(mu + eps softplus(var))
         float dan[48], dz[H];
 #pragma unroll
@@ -523,18 +534,8 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     outer_store<3, 2>(accZR, g + G_ZR, 48, 28, lane);
     outer_store<3, 2>(accN, g + G_N, 48, 28, lane);
     outer_store<2, 2>(accH0, g + G_H0, 24, 25, lane);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int k = 0; k < ROW; ++k) {
-            const float s = wave_sum(act41 ? aw2[c][k] : 0.0f);
-            if (lane == 0) g[G_H2 + c * ROW + k] = s;
-        }
-#pragma unroll
-    for (int k = 0; k < 28; ++k) {
-        const float s = wave_sum(act ? awo[k] : 0.0f);
-        if (lane == 0) g[G_O + k] = s;
-    }
+    outer_store<1, 2>(accW2, g + G_H2, 2, 25, lane);
+    outer_store<1, 2>(accO, g + G_O, 1, 28, lane);
     if (lane < RS_PFGRU_TRAIN_GRAD_FLOATS - G_END) g[G_END + lane] = 0.0f;        // the slab's padding
     if (lane == 0) {
         const float pred = l2w * l2s + l1w * 10.0f * l1s * inv_nel;

@@ -191,8 +191,6 @@ def run_test_environments_cnn(agents: Dict[int, Any], env_sets: Dict[str, tuple]
     vec.reset()
     obs = vec.refresh(src, det, inten, bkg, nob, rects)[0].clone()
     maps = HeatMaps(vec, L, enforce_boundaries=bool(enforce_grid_boundaries))
-    if maps.map_dimensions != (27, 27):
-        raise NotImplementedError("the CNN trunk kernels are built for 27 x 27 heat maps (enforce_grid_boundaries=True)")
     bank = None
     if use_predictor:
         bank = PredictorBank(N, A, seed=seed, device=dev)

@@ -29,6 +29,32 @@ def calculate_map_dimensions(grid_bounds, resolution_accuracy: float, offset: fl
             int(grid_bounds[1] * resolution_accuracy) + int(offset * resolution_accuracy))
 
 
+def heat_map_geometry(env: RadSearchVec, steps_per_episode: int, enforce_boundaries: bool, resolution_multiplier: float = 0.01,
+                      bounds_offset=(200.0, 500.0), grid_bounds=(1, 1), detector_step_size: float = 100.0):
+    """(resolution_accuracy, scaled_offset, map_dimensions) as CNNBase.__post_init__ derives them (RADTEAM_core.py:1727-1738): 27 x 27
+    cells with enforced walls, 147 x 147 without (the detectors may then leave the search area by up to steps_per_episode steps)."""
+    scale = 1 / float(env.cfg.bbox[3] - env.cfg.observation_area[1])                # env.scale (rad_search_env.py:435)
+    ra = calculate_resolution_accuracy(resolution_multiplier, scale)
+    if enforce_boundaries:
+        off = scale * max(bounds_offset)
+    else:
+        off = scale * (max(bounds_offset) + steps_per_episode * detector_step_size)
+    return ra, off, calculate_map_dimensions(grid_bounds, ra, off)
+
+
+def actor_stack_from(shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
+    """CNNBase.get_map_stack (RADTEAM_core.py:1791-1836) for owner a from the stored shared maps [B, 4, X, Y] and the owners' location
+    / prediction cells [B, A]: the dense [B, 6, X, Y] actor input {prediction, location, others, readings, visits, obstacles}."""
+    B, _, X, Y = shared.shape
+    loc = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
+    loc.scatter_(1, cells[:, a:a + 1], 1.0)
+    pm = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
+    pc = pcells[:, a:a + 1]
+    pm.scatter_(1, pc.clamp(min=0), (pc >= 0).float())
+    loc = loc.view(B, 1, X, Y)
+    return torch.cat([pm.view(B, 1, X, Y), loc, shared[:, 0:1] - loc, shared[:, 1:4]], dim=1)
+
+
 class HeatMaps:
     def __init__(self, env: RadSearchVec, steps_per_episode: int, resolution_multiplier: float = 0.01,
                  bounds_offset=(200.0, 500.0), grid_bounds=(1, 1), enforce_boundaries: bool = True,
@@ -36,13 +62,8 @@ class HeatMaps:
         self.lib = _lib.load()
         self.env = env
         self.N, self.A, self.L = env.num_envs, env.number_agents, steps_per_episode
-        scale = 1 / float(env.cfg.bbox[3] - env.cfg.observation_area[1])            # env.scale (rad_search_env.py:435)
-        self.resolution_accuracy = calculate_resolution_accuracy(resolution_multiplier, scale)
-        if enforce_boundaries:                                                       # RADTEAM_core.py:1727-1738
-            self.scaled_offset = scale * max(bounds_offset)
-        else:
-            self.scaled_offset = scale * (max(bounds_offset) + steps_per_episode * detector_step_size)
-        self.map_dimensions = calculate_map_dimensions(grid_bounds, self.resolution_accuracy, self.scaled_offset)
+        self.resolution_accuracy, self.scaled_offset, self.map_dimensions = heat_map_geometry(
+            env, steps_per_episode, enforce_boundaries, resolution_multiplier, bounds_offset, grid_bounds, detector_step_size)
         X, Y = self.map_dimensions
         base = (steps_per_episode + 1) * self.A                                      # :498
         tab = [(math.log(2 + 2 * c, base)) * 1 / math.log(2 * base, base) for c in range(base + 1)]
@@ -234,7 +255,12 @@ class CNNActor(nn.Module):
 
     def logits_from_maps(self, maps, cells, pcells, agent: int):
         """Owner `agent`'s logits for samples described by the resident shared maps [S,4,X,Y] + cell indices [S,A]:
-        HIP trunk (ConvTrunk) + the three Linear layers."""
+        HIP trunk (ConvTrunk) + the three Linear layers.  The trunk kernels K9 / K10 hold one 27 x 27 image in LDS (the walls-enforced
+        size every CLI of the reference trains with, main.py:311-316); any other map size -- 147 x 147 without enforced walls,
+        RADTEAM_core.py:1727-1738 -- takes the dense stack through the library convolutions (the same nn.Sequential)."""
+        if tuple(maps.shape[-2:]) != (27, 27):
+            with torch.backends.cudnn.flags(enabled=False):         # the native convolution: no MIOpen solver search for a one-off shape
+                return self.logits(actor_stack_from(maps, cells, pcells, agent))
         a = self.actor
         x = ConvTrunk.apply(maps, cells, pcells, agent, a[0].weight, a[0].bias, a[3].weight, a[3].bias, torch.is_grad_enabled())
         for layer in list(a)[6:-1]:
@@ -261,7 +287,11 @@ class CNNCritic(nn.Module):
         return self.critic(x).squeeze(-1)
 
     def value_from_maps(self, maps):
-        """V for samples given as resident shared maps [S,4,X,Y]: HIP trunk (ConvTrunk) + the Linear layers."""
+        """V for samples given as resident shared maps [S,4,X,Y]: HIP trunk (ConvTrunk) + the Linear layers (27 x 27 maps; other sizes
+        through the library convolutions, see CNNActor.logits_from_maps)."""
+        if tuple(maps.shape[-2:]) != (27, 27):
+            with torch.backends.cudnn.flags(enabled=False):
+                return self.critic(maps).squeeze(-1)
         c = self.critic
         x = ConvTrunk.apply(maps, None, None, -1, c[0].weight, c[0].bias, c[3].weight, c[3].bias, torch.is_grad_enabled())
         for layer in list(c)[6:]:

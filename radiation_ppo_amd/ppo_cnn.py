@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import _lib
 from .envs import RadSearchVec
-from .maps import CNNActor, CNNCritic, HeatMaps
+from .maps import CNNActor, CNNCritic, HeatMaps, actor_stack_from
 from .pfgru import PredictorBank
 from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
 
@@ -206,14 +206,18 @@ class CNNCollector:
         dev = env.device
         self.maps = HeatMaps(env, steps_per_episode, enforce_boundaries=bool(env.cfg.enforce_grid_boundaries))
         X, Y = self.maps.map_dimensions
-        if (X, Y) != (27, 27):
-            # RADTEAM_core.py:1727-1738: without enforced walls the maps grow to 147 x 147; the HIP trunk (csrc/rs_cnn.hip)
-            # is built for the walls-enforced 27 x 27 case the reference's CLIs train with (main.py:311-316)
-            raise NotImplementedError(f"heat maps of {X} x {Y} cells: the CNN trunk kernels are built for 27 x 27 maps "
-                                      "(enforce_grid_boundaries=True with the default 2700 cm bbox and (200, 500) observation area)")
         for ag in agents.values():
             if tuple(ag.map_dim) != (X, Y):
-                raise ValueError(f"agent {ag.id} was built for {ag.map_dim} maps, the environment produces {(X, Y)}")
+                raise ValueError(f"agent {ag.id} was built for {ag.map_dim} maps, the environment produces {(X, Y)} "
+                                 "(radiation_ppo_amd.maps.heat_map_geometry gives the size for an env)")
+            if (X, Y) != (27, 27):
+                # RADTEAM_core.py:1727-1738: without enforced walls the maps grow to 147 x 147.  K5 handles any size; the trunk goes
+                # through the dense stack and the library convolutions there (maps.CNNActor.logits_from_maps): update chunks sized so
+                # that one dense [chunk, 6, X, Y] stack stays near 1 GB
+                ag.chunk = min(ag.chunk, max(64, (1 << 28) // (6 * X * Y)))
+        need = self.T * self.N * 4 * X * Y * 4
+        if need > 200e9:
+            raise MemoryError(f"{X} x {Y} heat maps: the epoch's stored maps would take {need / 1e9:.0f} GB; use fewer envs")
         self.buf = RolloutBuffer(self.T, self.N, self.A, _lib.RS_OBS_DIM, dev)
         # per step only the four shared maps and the cell indices are stored; actor stacks are rebuilt on demand
         self.shared = torch.zeros(self.T, self.N, 4, X, Y, dtype=torch.float32, device=dev)
@@ -250,15 +254,7 @@ class CNNCollector:
             self.predictor.reset()                                  # ac.reset_hidden() (test_cnn/train.py:686)
 
     def actor_stack_from(self, shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
-        """CNNBase.get_map_stack (:1791-1836) for owner a from the stored shared maps: [B,6,X,Y]."""
-        B, _, X, Y = shared.shape
-        loc = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
-        loc.scatter_(1, cells[:, a:a + 1], 1.0)
-        pm = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
-        pc = pcells[:, a:a + 1]
-        pm.scatter_(1, pc.clamp(min=0), (pc >= 0).float())
-        loc = loc.view(B, 1, X, Y)
-        return torch.cat([pm.view(B, 1, X, Y), loc, shared[:, 0:1] - loc, shared[:, 1:4]], dim=1)
+        return actor_stack_from(shared, cells, pcells, a)
 
     @torch.no_grad()
     def _round(self, mask: Optional[torch.Tensor] = None):

@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from .envs import RadSearch, RadSearchVec
 from .logger import EpochLogger, convert_json, setup_logger_kwargs
-from .maps import CNNCritic
+from .maps import CNNCritic, heat_map_geometry
 from .ppo import Collector, FusedCollector, VecAgentPPO
 from .ppo_cnn import CNNAgentPPO, CNNCollector
 from .rada2c import RNNAgentPPO, RNNCollector
@@ -111,8 +111,10 @@ class train_PPO:
         self.epochs_done = 0
         if self.actor_critic_architecture == "cnn":
             gc = gco = None
+            # CNNBase.__post_init__ (RADTEAM_core.py:1727-1738): 27 x 27 maps with enforced walls, 147 x 147 without
+            kw.setdefault("map_dim", heat_map_geometry(self.vec, self.steps_per_episode, bool(self.vec.cfg.enforce_grid_boundaries))[2])
             if self.global_critic_flag:                                        # train.py:191-206
-                gc = CNNCritic().to(self.vec.device)
+                gc = CNNCritic(map_dim=kw["map_dim"]).to(self.vec.device)
                 gco = torch.optim.Adam(gc.parameters(), lr=kw.get("critic_learning_rate", 1e-3))
             kw.pop("GlobalCriticOptimizer", None)
             self.collector = None

@@ -18,7 +18,7 @@ def load(d, counter):
             name = r["Kernel_Name"]
             if "rs_" not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             if "rs_step_kernel" in short:
                 short += "@grid%s" % r["Grid_Size"]
             acc[short].append(float(r["Counter_Value"]))

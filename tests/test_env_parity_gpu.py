@@ -76,7 +76,7 @@ def _compare(vec, outs, refs, rets, tag):
         assert team[n] == np.float32(r["team_reward"]), (tag, n)
 
 
-def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="reference", seed=0, **opts):
+def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="reference", seed=0, allow_err=0, **opts):
     vec, specs, geom = _make(N, A, obst, enforce, group, base, falloff, **opts)
     refs = [RadSearchOracle(PhiloxDraws(SEED, base + n), number_agents=A, obstruction_count=obst,
                             enforce_grid_boundaries=enforce, falloff=falloff, layout_fn=fn, **opts) for n, fn in specs]
@@ -108,8 +108,10 @@ def _run(N, A, obst, enforce, steps, group=1, ep_len=25, base=0, falloff="refere
             torch.cuda.synchronize()
             _compare(vec, outs, refs, rets, f"reset@{t}")
             t_in_ep[mask] = 0
-    assert vec.error_flags() == 0
-    assert all(e.err == 0 for e in refs)
+    ref_err = 0
+    for e in refs:
+        ref_err |= e.err
+    assert vec.error_flags() == ref_err and (ref_err & ~allow_err) == 0, (vec.error_flags(), ref_err)
     return refs
 
 
@@ -121,8 +123,10 @@ def test_obstacle_free_single_agent_enforced():
 def test_debug_spawn(A, obst):
     """DEBUG=True (rad_search_env.py:387-389, :782-785, :1043-1090; the oracle's restatement is pinned to the reference by
     tests/golden/envopt_debug_a1.npz): source (500, 500), detector (1000, 1000) unless it falls into a rectangle, no spawn resampling,
-    intensity 1e6, background 0 -- bit-exact like every other env output."""
-    refs = _run(N=64, A=A, obst=obst, enforce=True, steps=40, seed=5, DEBUG=True)
+    intensity 1e6, background 0 -- bit-exact like every other env output.  With rectangles the fixed source may lie inside one (the
+    reference resamples nothing under DEBUG; visilibity is then undefined): kernel and oracle raise the same RS_ENVERR_NO_PATH bit."""
+    from radiation_ppo_amd import _lib
+    refs = _run(N=64, A=A, obst=obst, enforce=True, steps=40, seed=5, allow_err=_lib.ENVERR_NO_PATH if obst else 0, DEBUG=True)
     assert all(e.src == (500, 500) and e.intensity == 1000000 and e.bkg_intensity == 0 for e in refs)
 
 

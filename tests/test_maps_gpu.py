@@ -64,6 +64,42 @@ def test_heat_maps_match_oracle(A, obst):
     assert int(hm.field("err").max().item()) == 0
 
 
+def test_heat_maps_without_enforced_walls_match_oracle():
+    """enforce_grid_boundaries=False (the env's own default, rad_search_env.py:328): the maps grow to 147 x 147 cells
+    (CNNBase.__post_init__, RADTEAM_core.py:1727-1738: the offset covers steps_per_episode steps beyond the search area) and detectors
+    do leave the area.  K5 float32-exact against the MapsBuffer oracle at that size, 2 agents."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import HeatMaps, heat_map_geometry
+    N, L, A = 12, 120, 2
+    env = RadSearchVec(N, number_agents=A, obstruction_count=0, enforce_grid_boundaries=False, seed=SEED)
+    hm = HeatMaps(env, steps_per_episode=L, enforce_boundaries=False)
+    ra, off, dims = heat_map_geometry(env, L, False)
+    assert hm.map_dimensions == dims == (147, 147) and ra == 22.0
+    refs = [RadSearchOracle(PhiloxDraws(SEED, n), number_agents=A, obstruction_count=0, enforce_grid_boundaries=False) for n in range(N)]
+    bufs = [[MapsOracle(steps_per_episode=L, number_of_agents=A, resolution_accuracy=ra, offset=off) for _ in range(A)] for _ in range(N)]
+    assert bufs[0][0].dims == (147, 147)
+    obs_t = env.reset()[0]
+    cur = [e._ret[0] for e in refs]
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        pred = torch.rand(N, A, 2, generator=torch.Generator().manual_seed(t)).cuda() * 1.2
+        hm.update(obs_t, pred)
+        actor, critic = (x.cpu().numpy() for x in hm.stacks())
+        pc = pred.cpu().numpy()
+        for n in range(0, N, 3):
+            od = {i: np.array(cur[n][i], dtype=np.float64) for i in range(A)}
+            for i in range(A):
+                m = bufs[n][i].observation_to_map(od, i, (float(pc[n, i, 0]), float(pc[n, i, 1])))
+                assert np.array_equal(actor[n, i], np.stack([m[0], m[1], m[2], m[3], m[4], m[5]])), (t, n, i)
+        acts = np.full((N, A), 0, dtype=np.int8)                     # everybody walks left: out of the search area after a few steps
+        acts[:, 1] = rng.integers(0, 9, size=N)
+        obs_t = env.step(torch.from_numpy(acts).cuda())[0]
+        for n, e in enumerate(refs):
+            cur[n] = e.step({a: int(acts[n, a]) for a in range(A)})[0]
+    assert float(obs_t[:, 0, 1].min()) < 0.0                           # scaled x below the area: only representable on the big map
+    assert int(hm.field("err").max().item()) == 0
+
+
 def test_cnn_modules_match_reference_outputs(golden_dir):
     """Batched CNN actor / critic == the reference's batch-1 networks on the golden inputs (same state_dict keys)."""
     from radiation_ppo_amd.maps import CNNActor, CNNCritic

@@ -106,14 +106,28 @@ def test_cnn_checkpoint_files_match_reference_names(tmp_path, golden_dir):
     assert len(sim2.loggers[0].rows) == 1 and sim2.loggers[0].rows[0]["Epoch"] == 2
 
 
-def test_cnn_rejects_unenforced_boundaries_up_front():
-    """enforce_grid_boundaries=False grows the heat maps to 147 x 147 (RADTEAM_core.py:1727-1738); the HIP trunk is built for
-    27 x 27: the trainer must refuse at construction, not die in a kernel-side assert."""
+def test_cnn_trains_without_enforced_boundaries():
+    """enforce_grid_boundaries=False grows the heat maps to 147 x 147 (RADTEAM_core.py:1727-1738).  The trunk kernels K9 / K10 hold one
+    27 x 27 image in LDS; this size takes the dense stack through the library convolutions with the same modules, K5 and the env
+    kernels unchanged: train_PPO sizes the networks from the env (Linear(16 * 73 * 73, 32)), collects and updates."""
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.train import train_PPO
-    env = RadSearchVec(4, number_agents=1, obstruction_count=0, enforce_grid_boundaries=False, seed=1)
-    with pytest.raises(NotImplementedError, match="27 x 27"):
-        train_PPO(env=env, logger_kwargs={}, number_of_agents=1, global_critic_flag=False, steps_per_epoch=8, steps_per_episode=4)
+    env = RadSearchVec(4, number_agents=2, obstruction_count=1, enforce_grid_boundaries=False, seed=1)
+    sim = train_PPO(env=env, logger_kwargs={}, number_of_agents=2, global_critic_flag=True, steps_per_epoch=8, steps_per_episode=4,
+                    total_epochs=2, ppo_kwargs=dict(train_pi_iters=2, train_v_iters=2))
+    assert sim.collector.maps.map_dimensions == (147, 147) and sim.agents[0].pi.actor[6].in_features == 16 * 73 * 73
+    before = torch.cat([p.detach().reshape(-1).clone() for p in sim.agents[1].pi.parameters()])
+    sim.train()
+    after = torch.cat([p.detach().reshape(-1) for p in sim.agents[1].pi.parameters()])
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    rows = sim.loggers[0].rows
+    assert len(rows) == 2 and all(np.isfinite(float(r[k])) for r in rows for k in ("loss_policy", "loss_critic", "kl_divergence", "Entropy"))
+    # the dense stack the library path convolves == what the K5 stack kernel materialises for the same state
+    col = sim.collector
+    shared, cells, pcells = col.maps.shared_maps(), col.maps.field("cell").long(), col.maps.field("pred_cell").long()
+    actor, _ = col.maps.stacks()
+    for a in range(2):
+        assert torch.equal(col.actor_stack_from(shared, cells, pcells, a), actor[:, a])
 
 
 @pytest.mark.parametrize("arch", ["ff", "rnn", "cnn"])
