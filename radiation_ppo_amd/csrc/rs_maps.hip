@@ -36,6 +36,7 @@ struct rs_maps {
 
 #define RS_MAPERR_RING_FULL 1u
 #define RS_MAPERR_VISIT_OVERFLOW 2u
+#define RS_MAPERR_OFF_MAP 4u            // a coordinate beyond the map (the reference's numpy indexing raises IndexError there)
 
 // ------------------------------------------------------------------------------------------------
 // median of the readings recorded in `cell` (statistics.median: mean of the two middle values when even).
@@ -123,8 +124,13 @@ __global__ void __launch_bounds__(64) rs_maps_update_kernel(RsMapsParams M, RsPa
     for (int a = 0; a < RS_MAX_AGENTS; ++a) {
         cur[a] = 0;
         if (a < A) {
-            const int cx = (int)(((double)E.ax[(size_t)a * E.N + n] * E.scale) * M.ra);
-            const int cy = (int)(((double)E.ay[(size_t)a * E.N + n] * E.scale) * M.ra);
+            int cx = (int)(((double)E.ax[(size_t)a * E.N + n] * E.scale) * M.ra);
+            int cy = (int)(((double)E.ay[(size_t)a * E.N + n] * E.scale) * M.ra);
+            // a NEGATIVE index is legal numpy: map[-k] is the k-th cell from the end.  Without enforced walls a detector left of /
+            // below the area lands there (what the 147 x 147 map's extra cells absorb, RADTEAM_core.py:1727-1738)
+            if (cx < 0) cx += M.X;
+            if (cy < 0) cy += M.Y;
+            if (cx < 0 || cx >= M.X || cy < 0 || cy >= M.Y) err |= RS_MAPERR_OFF_MAP;
             cur[a] = min(max(cx, 0), M.X - 1) * M.Y + min(max(cy, 0), M.Y - 1);
         }
     }

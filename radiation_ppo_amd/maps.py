@@ -47,7 +47,8 @@ def actor_stack_from(shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Te
     / prediction cells [B, A]: the dense [B, 6, X, Y] actor input {prediction, location, others, readings, visits, obstacles}."""
     B, _, X, Y = shared.shape
     loc = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
-    loc.scatter_(1, cells[:, a:a + 1], 1.0)
+    lc = cells[:, a:a + 1]
+    loc.scatter_(1, lc.clamp(min=0), (lc >= 0).float())             # -1: no position recorded yet (fresh maps)
     pm = torch.zeros(B, X * Y, dtype=torch.float32, device=shared.device)
     pc = pcells[:, a:a + 1]
     pm.scatter_(1, pc.clamp(min=0), (pc >= 0).float())

@@ -109,13 +109,14 @@ def test_cnn_checkpoint_files_match_reference_names(tmp_path, golden_dir):
 def test_cnn_trains_without_enforced_boundaries():
     """enforce_grid_boundaries=False grows the heat maps to 147 x 147 (RADTEAM_core.py:1727-1738).  The trunk kernels K9 / K10 hold one
     27 x 27 image in LDS; this size takes the dense stack through the library convolutions with the same modules, K5 and the env
-    kernels unchanged: train_PPO sizes the networks from the env (Linear(16 * 73 * 73, 32)), collects and updates."""
+    kernels unchanged: train_PPO sizes the networks from the env (Linear(16 * 73 * 73, 32) for 120-step episodes), collects and updates."""
     from radiation_ppo_amd.envs import RadSearchVec
     from radiation_ppo_amd.train import train_PPO
     env = RadSearchVec(4, number_agents=2, obstruction_count=1, enforce_grid_boundaries=False, seed=1)
     sim = train_PPO(env=env, logger_kwargs={}, number_of_agents=2, global_critic_flag=True, steps_per_epoch=8, steps_per_episode=4,
                     total_epochs=2, ppo_kwargs=dict(train_pi_iters=2, train_v_iters=2))
-    assert sim.collector.maps.map_dimensions == (147, 147) and sim.agents[0].pi.actor[6].in_features == 16 * 73 * 73
+    # the offset covers steps_per_episode detector steps beyond the area: 31 x 31 cells for 4-step episodes (147 x 147 for 120)
+    assert sim.collector.maps.map_dimensions == (31, 31) and sim.agents[0].pi.actor[6].in_features == 16 * 15 * 15
     before = torch.cat([p.detach().reshape(-1).clone() for p in sim.agents[1].pi.parameters()])
     sim.train()
     after = torch.cat([p.detach().reshape(-1) for p in sim.agents[1].pi.parameters()])
