@@ -124,7 +124,8 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
     recurrent = hasattr(agent.agent, "gru_cell")                  # RAD-A2C: hidden = ac.reset_hidden() per episode (evaluate.py:357-360)
     if recurrent:
         from .pfgru import PredictorBank, hash_uniform
-        bank = PredictorBank(N, 1, seed=seed, carry_hidden=True, device=dev)
+        bank = PredictorBank(N, 1, hidden_size=agent.agent.rec, seed=seed, carry_hidden=True, device=dev,
+                             impl="hip" if agent.agent.fused_pfgru else "torch")
         bank.cells[0] = agent.agent.model
         bank.reset()
         gk = (bank._base[0] * 1000003 + 5).view(-1, 1) * 1048583 + torch.arange(agent.agent.hid, dtype=torch.int64, device=dev).view(1, -1)
@@ -133,7 +134,7 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
         x = obs.clone()
         stat.standardize(obs[..., 0], out=x[..., 0])
         vec.action_uniforms(u)
-        if recurrent and agent.agent.hid == 24 and hasattr(agent, "policy_step_hip"):
+        if recurrent and agent.agent.fused_policy and hasattr(agent, "policy_step_hip"):
             a = torch.empty(N, dtype=torch.int64, device=dev)             # K14: GRU cell + heads + draw in one launch
             agent.policy_step_hip(x[:, 0].contiguous(), bank.predict(x)[:, 0].contiguous(), hid, u=u[:, 0].contiguous(), h_out=hid, act=a)
         elif recurrent:

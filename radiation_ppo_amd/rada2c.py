@@ -44,14 +44,23 @@ from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
 from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
 
 
-class _SeqPt(nn.Module):
-    """SeqPt (RADA2C_core.py:351-391)."""
+def _mlp_tanh(sizes) -> nn.Sequential:
+    """mlp(sizes, nn.Tanh) with the trailing activation dropped (RADA2C_core.py:363-368): Linear-Tanh-...-Linear, layers at the even
+    indices of the Sequential as in the reference's state_dict keys (Woms.0, Woms.2, ...)."""
+    layers: List[nn.Module] = []
+    for i in range(len(sizes) - 1):
+        layers += [nn.Linear(int(sizes[i]), int(sizes[i + 1])), nn.Tanh()]
+    return nn.Sequential(*layers[:-1])
 
-    def __init__(self, input_size: int, hid: int, pol: int, val: int, act_dim: int):
+
+class _SeqPt(nn.Module):
+    """SeqPt (RADA2C_core.py:351-391).  pol / val: the hidden widths of the two heads (one entry each in the reference's defaults)."""
+
+    def __init__(self, input_size: int, hid: int, pol, val, act_dim: int):
         super().__init__()
         self.seq_model = nn.GRU(input_size, hid, 1)
-        self.Woms = nn.Sequential(nn.Linear(hid, pol), nn.Tanh(), nn.Linear(pol, act_dim))     # mlp(...)[:-1] (:363-366)
-        self.Valms = nn.Sequential(nn.Linear(hid, val), nn.Tanh(), nn.Linear(val, 1))         # (:367-368)
+        self.Woms = _mlp_tanh([hid, *pol, act_dim])                                            # mlp(...)[:-1] (:363-366)
+        self.Valms = _mlp_tanh([hid, *val, 1])                                                 # (:367-368)
 
 
 class _LinearRows(torch.autograd.Function):
@@ -101,13 +110,16 @@ class RNNModelActorCritic(nn.Module):
     def __init__(self, obs_dim: int = 11, act_dim: int = 8, hidden=((24,),), hidden_sizes_pol=((32,),), hidden_sizes_val=((32,),),
                  hidden_sizes_rec=(24,), pad_dim: int = 2, net_type: str = "rnn", seed: int = 0, **unused: Any):
         super().__init__()
-        hid, pol, val = int(hidden[0][0]), int(hidden_sizes_pol[0][0]), int(hidden_sizes_val[0][0])
-        if len(hidden_sizes_pol) != 1 or len(hidden_sizes_val) != 1:
-            raise NotImplementedError("one hidden layer per head (the reference's defaults l_pol = l_val = 1, main.py:131-134)")
-        self.hid, self.obs_dim, self.act_dim = hid, obs_dim, act_dim
+        hid = int(hidden[0][0])
+        pol, val = [int(v) for v in hidden_sizes_pol[0]], [int(v) for v in hidden_sizes_val[0]]     # [*hidden_size[1]] / [*hidden_size[2]] (:363-368)
+        self.hid, self.obs_dim, self.act_dim, self.rec = hid, obs_dim, act_dim, int(hidden_sizes_rec[0])
         self.pi = _Actor(obs_dim + pad_dim, hid, pol, val, act_dim)
-        self.model = PFGRUCell(input_size=obs_dim - 8, obs_size=obs_dim - 8, hidden_size=int(hidden_sizes_rec[0]))
+        self.model = PFGRUCell(input_size=obs_dim - 8, obs_size=obs_dim - 8, hidden_size=self.rec)
         self.num_particles, self.alpha = 40, 0.7
+        # the fused kernels are built for the reference's default sizes (main.py:131-134): GRU(13, 24), 32-unit single-layer heads, 8
+        # actions (K12 / K14 / K15) and a 24-unit PFGRU (K11 / K13); any other size runs the same arithmetic composed from library ops
+        self.fused_policy = (obs_dim, pad_dim, hid, pol, val, act_dim) == (11, 2, 24, [32], [32], 8)
+        self.fused_pfgru = self.rec == 24 and obs_dim == 11
 
     # ---- batched arithmetic
     def gru_cell(self, x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
@@ -650,10 +662,10 @@ class RNNAgentPPO:
                 sl = slice(lo, min(lo + self.episode_chunk, E))
                 if draws_for is not None:
                     d = draws_for(it, sl)
-                elif self.device.type == "cuda":
+                elif self.device.type == "cuda" and self.agent.fused_pfgru:
                     d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0])
                 else:
-                    d = HashDraws(B.key[sl] * 64 + 1 + it)
+                    d = HashDraws(B.key[sl] * 64 + 1 + it, H=self.agent.rec, hid=self.agent.hid)
                 if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
                     # K13: the episode loop, the loss and its back-propagation through time in one launch
                     loss, g, _ = self.model_pass_hip(B, sl, d)
@@ -687,7 +699,7 @@ class RNNAgentPPO:
         with torch.cuda.stream(self._side), torch.no_grad():
             for lo in range(0, E, self.episode_chunk):
                 Bc = B.chunk(slice(lo, min(lo + self.episode_chunk, E)))
-                loc = self._pfgru_pass_hip(Bc.X, HashDraws(Bc.key * 64 + 17 + it), Bc.lens_host)
+                loc = self._pfgru_pass_hip(Bc.X, HashDraws(Bc.key * 64 + 17 + it), Bc.lens_host)      # (fused_pfgru only: see update_agent)
                 loc.record_stream(main)
                 out.append(loc)
             ev = torch.cuda.Event()
@@ -708,7 +720,7 @@ class RNNAgentPPO:
                 pass
             elif isinstance(draws, RecordedKernelDraws) and X.is_cuda:
                 loc = self._pfgru_pass_hip_recorded(X, draws)
-            elif isinstance(draws, HashDraws) and X.is_cuda:
+            elif isinstance(draws, HashDraws) and X.is_cuda and ac.fused_pfgru:
                 loc = self._pfgru_pass_hip(X, draws, B.lens_host)          # K11 with carried particle sets: one launch per step
             else:
                 loc, _ = self._pfgru_pass(X[..., :3], draws, False)
@@ -716,13 +728,13 @@ class RNNAgentPPO:
         # the GRU over the whole (padded) episode batch in one sequence call, as grad_step does (:564): states past an episode's
         # end are computed and never used (weight 0)
         g = ac.pi.logits_net.v_net.seq_model
-        if X.is_cuda and ac.hid == 24 and getattr(self, "use_k12", True):
+        if X.is_cuda and ac.hid == 24 and g.input_size == 13 and getattr(self, "use_k12", True):
             # K12: the recurrence and its back-propagation through time in one launch each
             hs = GRUSequence.apply(torch.cat((X, loc), dim=2), h, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
         else:
             with torch.backends.cudnn.flags(enabled=False):    # (the library path; on the GPU MIOpen's RNN backward is slower than native)
                 hs, _ = g(torch.cat((X, loc), dim=2), h.unsqueeze(0).contiguous())
-        if X.is_cuda and ac.hid == 24 and getattr(self, "use_k15", True):
+        if X.is_cuda and ac.fused_policy and getattr(self, "use_k15", True):
             # K15: heads + per-sample loss + their back-propagation in one launch
             v = ac.pi.logits_net.v_net
             flat = lambda t: t.reshape(L * E).contiguous()
@@ -761,7 +773,7 @@ class RNNAgentPPO:
         stats = torch.zeros(7, dtype=torch.float64, device=self.device)
         for ci, lo in enumerate(range(0, E, self.episode_chunk)):
             sl = slice(lo, min(lo + self.episode_chunk, E))
-            d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 17 + it)
+            d = draws_for(it, sl) if draws_for is not None else HashDraws(B.key[sl] * 64 + 17 + it, H=self.agent.rec, hid=self.agent.hid)
             loss, st = self.a2c_losses(B, sl, d, loc=None if locs is None else locs[ci])
             loss.backward()
             stats += st
@@ -779,7 +791,7 @@ class RNNAgentPPO:
         model_loss = self.update_model(B)
         self.pi_optimizer.zero_grad(set_to_none=True)
         kk, term, s = 0, False, None
-        ahead = self.device.type == "cuda" and getattr(self, "use_prefetch", True)
+        ahead = self.device.type == "cuda" and self.agent.fused_pfgru and getattr(self, "use_prefetch", True)
         nxt = self.loc_prefetch(B, 0) if ahead else None
         while not term and kk < self.train_pi_iters:
             cur = nxt
@@ -838,8 +850,9 @@ class RNNCollector:
         self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
         self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
         self.h = torch.zeros(self.A, self.N, hid, dtype=torch.float32, device=dev)                 # GRU states
-        self.bank = PredictorBank(self.N, self.A, hidden_size=24, seed=int(env.cfg.seed), env_id_base=int(env.cfg.env_id_base),
-                                  carry_hidden=True, device=dev)
+        fused_pf = torch.device(dev).type == "cuda" and all(ag.agent.fused_pfgru for ag in agents.values())
+        self.bank = PredictorBank(self.N, self.A, hidden_size=agents[0].agent.rec, seed=int(env.cfg.seed),
+                                  env_id_base=int(env.cfg.env_id_base), carry_hidden=True, device=dev, impl="hip" if fused_pf else "torch")
         for a, ag in agents.items():                                         # the bank evaluates the agents' own PFGRU modules
             self.bank.cells[a] = ag.agent.model
         self.episodes_begun = torch.zeros(self.N, dtype=torch.int64, device=dev)
@@ -853,7 +866,7 @@ class RNNCollector:
         self._row_f = torch.zeros(3, self.N, self.A, dtype=torch.float32, device=dev)
         self._src = torch.zeros(self.N, 2, dtype=torch.float32, device=dev)
         # K14 (rs_rnn_policy_step): GRU cell + heads + draw in one launch instead of ~35 library kernels per call
-        self.use_k14 = torch.device(dev).type == "cuda" and all(ag.agent.hid == 24 for ag in agents.values())
+        self.use_k14 = torch.device(dev).type == "cuda" and all(ag.agent.fused_policy for ag in agents.values())
         self._k_act = torch.zeros(self.A, self.N, dtype=torch.int64, device=dev)
         self._k_f = torch.zeros(self.A, 3, self.N, dtype=torch.float32, device=dev)          # logp, value, bootstrap value
         self.obs = None

@@ -157,3 +157,24 @@ def test_sorted_episode_batch_gives_the_same_update():
     for k in ("loss_policy", "loss_critic", "loss_predictor", "kl_divergence", "Entropy", "LocLoss"):
         assert np.isclose(getattr(a[0], k), getattr(b[0], k), rtol=2e-4, atol=1e-6), (k, getattr(a[0], k), getattr(b[0], k))
     assert float((a[1] - b[1]).abs().max()) <= 2.5e-3            # Adam steps of lr <= 5e-3: same direction everywhere
+
+
+def test_other_layer_sizes_follow_the_references_constructor():
+    """hidden / hidden_sizes_pol / hidden_sizes_val / hidden_sizes_rec other than main.py's defaults (RADA2C_core.py:351-368, :483-515:
+    mlp([hid, *pol, act_dim]) with Tanh between the layers): state_dict names as the reference numbers them (Woms.0, Woms.2, Woms.4),
+    and an update runs through the library-op composition (the fused kernels are built for the default sizes only)."""
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNModelActorCritic
+    ac = RNNModelActorCritic(hidden=((16,),), hidden_sizes_pol=((20, 12),), hidden_sizes_val=((10,),), hidden_sizes_rec=(12,))
+    sd = ac.state_dict()
+    v = "pi.logits_net.v_net."
+    assert sd[v + "seq_model.weight_ih_l0"].shape == (48, 13) and sd[v + "Woms.0.weight"].shape == (20, 16)
+    assert sd[v + "Woms.2.weight"].shape == (12, 20) and sd[v + "Woms.4.weight"].shape == (8, 12) and sd[v + "Valms.2.weight"].shape == (1, 10)
+    assert sd["model.fc_z.weight"].shape == (12, 15) and not ac.fused_policy and not ac.fused_pfgru
+    assert RNNModelActorCritic().fused_policy and RNNModelActorCritic().fused_pfgru
+    ag = RNNAgentPPO(id=0, device="cpu", train_pi_iters=2, train_pfgru_iters=1,
+                     actor_critic_args=dict(hidden=((16,),), hidden_sizes_pol=((20, 12),), hidden_sizes_val=((10,),), hidden_sizes_rec=(12,)))
+    B, _ = _episodes()
+    before = torch.cat([p.detach().reshape(-1).clone() for p in ag.agent.parameters()])
+    r = ag.update_agent(B)
+    after = torch.cat([p.detach().reshape(-1) for p in ag.agent.parameters()])
+    assert np.isfinite([r.loss_policy, r.loss_critic, r.loss_predictor, r.kl_divergence]).all() and not torch.equal(before, after)

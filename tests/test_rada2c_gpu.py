@@ -485,3 +485,23 @@ def test_update_agent_with_prefetched_pfgru_passes_equals_the_serial_schedule():
     for k in ("loss_policy", "loss_critic", "kl_divergence", "Entropy", "ClipFrac", "LocLoss"):
         assert getattr(a[0], k) == getattr(b[0], k), (k, getattr(a[0], k), getattr(b[0], k))
     assert torch.equal(a[1], b[1])
+
+
+def test_non_default_layer_sizes_train_on_the_gpu():
+    """RAD-A2C with layer sizes other than the reference's defaults: collector and update run through the library-op composition on the
+    GPU (K11 - K15 are built for GRU(13, 24), 32-unit heads and a 24-unit PFGRU; the env and the statistics kernels are shared)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
+    N, T, L = 24, 16, 6
+    torch.manual_seed(5)
+    env = RadSearchVec(N, number_agents=1, obstruction_count=1, enforce_grid_boundaries=True, seed=SEED)
+    args = dict(hidden=((16,),), hidden_sizes_pol=((20, 12),), hidden_sizes_val=((10,),), hidden_sizes_rec=(12,))
+    agents = {0: RNNAgentPPO(id=0, steps_per_epoch=T, steps_per_episode=L, train_pi_iters=2, train_pfgru_iters=2, seed=3, actor_critic_args=args)}
+    col = RNNCollector(env, agents, T, L, use_graph=False)
+    assert not col.use_k14 and col.bank.impl == "torch" and col.bank.H == 12
+    col.collect()
+    _replay_check(col, agents, N, T, L, 1, stride=4)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in agents[0].agent.parameters()])
+    r = col.update()[0]
+    after = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()])
+    assert np.isfinite([r.loss_policy, r.loss_critic, r.loss_predictor, r.kl_divergence, r.LocLoss]).all() and not torch.equal(before, after)
