@@ -53,10 +53,12 @@ ROLLOUT_BYTES_PER_ENV_STEP = 77
 #   backward 2*(512+512+4096+4096+704) [actor dW3,dh2,dW2,dh1,dW1] + 2*(64+64+4096+4096+704) = 37 888
 PPO_GRAD_FLOPS_PER_SAMPLE = 58240
 # CNN trunk (conv3x3(Cin->8)-ReLU-pool-conv3x3(8->16)-ReLU) multiply-adds per 27x27 image, zero-padded borders counted:
-#   forward: conv1 729*9*Cin*8 + conv2 169*9*8*16;  backward (weight gradients + dP1): dW2 + dP1 = 2 * conv2, dW1 = conv1 / 4
-#   (only the arg-max pixel of each pool window carries gradient)
+#   forward: conv1 729*9*4*8 over the 4 DENSE planes (+ 2*9*8 stamp adds for the actor's two one-hot channels, round 3: those channels
+#   are no longer convolved) + conv2 169*9*8*16;  backward (weight gradients + dP1): dW2 + dP1 = 2 * conv2, dW1 = conv1 / 4 (only the
+#   arg-max pixel of each pool window carries gradient) (+ 2*72 gathers).  Actor 384 768 MAC forward (round 2 counted 489 744 for six
+#   dense channels), critic 384 624.
 def cnn_trunk_flops(cin: int, backward: bool) -> float:
-    c1, c2 = 729 * 9 * cin * 8, 169 * 9 * 8 * 16
+    c1, c2 = 729 * 9 * 4 * 8 + (144 if cin == 6 else 0), 169 * 9 * 8 * 16
     return 2.0 * ((2 * c2 + c1 / 4) if backward else (c1 + c2))
 
 
@@ -266,6 +268,16 @@ def pmc_traffic():
         return None
 
 
+def unit_traffic(kernel: str):
+    """(HBM bytes per unit, source note) of a kernel from the committed counter passes (profiles/r*_pmc_traffic.json `per_unit`: measured
+    at the drivers' sizes by scripts/pmc_r3.sh and scaled per image / env-step / particle-step), or (None, None)."""
+    d = pmc_traffic()
+    u = (d or {}).get("per_unit", {}).get(kernel)
+    if not u:
+        return None, None
+    return float(u["hbm_bytes_per_unit"]), f"{d['source']}; {u['hbm_bytes_per_unit']:.0f} B per {u['unit']} x the units of this launch"
+
+
 # ------------------------------------------------------------------------------------------------ configs 3 and 4
 def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     """BASELINE config 3: single agent, 1 source + random obstructions (U{1..5} rectangles per env, resampled every
@@ -303,6 +315,8 @@ def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     env64.reset()
     k1s = time_step_kernel(env64, reps=200)
     del env64
+    tr_roll, src_roll = unit_traffic("rs_rollout16_kernel<true>")
+    tr_step, src_step = unit_traffic("rs_step4_kernel")
     out = {"workload": "single-agent RadSearch, 1 source + U{1..5} random rectangles per env, 8192 envs, 2x64 MLP, 480 steps/epoch",
            "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
@@ -310,7 +324,8 @@ def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
            "roofline": grad_roofline(ev["rs_ppo_grad"], stops, ag[0].train_pi_iters, N * T),
            "config5_note": "config 5 (32 768 envs x 4 agents + obstacles on 8 GPUs) has config 4's per-GPU workload: 4096 envs x 4 agents",
            "roofline_rollout": {"bound": "hbm", "kernel": "rs_rollout16_kernel<true>", "achieved": roll_gbs, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": roll_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": roll_ms,
+                                "unit": "GB/s", "frac": roll_gbs / HBM_PEAK_GBS, "traffic": None if tr_roll is None else tr_roll * N * T,
+                                "traffic_source": src_roll, "avg_launch_ms": roll_ms,
                                 "bytes_per_launch": ROLLOUT_BYTES_PER_ENV_STEP * N * T, "us_per_lock_step": 1e3 * roll_ms / T,
                                 "note": "one launch = 480 lock-steps of 8192 envs with the policy in the loop; latency bound "
                                         "(f64 env chain + visibility tests per lane), not HBM bound"},
@@ -320,8 +335,9 @@ def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
                                  "env_only_steps_per_s_shared_geometry_64": N / (k1s["avg_ms"] * 1e-3),
                                  "achieved": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": None, "bytes_per_launch": K1_BYTES_PER_AGENT_STEP * N,
-                                 "note": "157 B/agent-step counted (obstacle rectangles and cached geodesics not counted)"},
+                                 "traffic": None if tr_step is None else tr_step * N, "traffic_source": src_step,
+                                 "bytes_per_launch": K1_BYTES_PER_AGENT_STEP * N,
+                                 "note": "157 B/agent-step counted (obstacle rectangles 16 B x O and cached geodesics 32 B x O per env not counted)"},
            "gae_ms": gae_ms}
     flags = env.error_flags()
     out["env_error_flags"] = flags
@@ -376,9 +392,13 @@ def run_config4(dev, iters: int = 1, warmup: int = 1, cpu: bool = True):
             # actor launches (6 channels) outnumber critic launches (4 channels) 4:1 with a global critic
             fl = (4 * cnn_trunk_flops(6, bwd) + cnn_trunk_flops(4, bwd)) / 5.0 * chunk
             tf = fl / (ms * 1e-3) / 1e12
+            kn = "rs_cnn_bwd_kernel" if bwd else "rs_cnn_fwd_kernel"
+            t6, src6 = unit_traffic(kn + "<6>")
+            t4, _ = unit_traffic(kn + "<4>")
             out["roofline_cnn_bwd" if bwd else "roofline_cnn_fwd"] = {
                 "bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms, "launches_timed": len(ds),
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None if t6 is None or t4 is None else (4 * t6 + t4) / 5.0 * chunk,
+                "traffic_source": src6, "avg_launch_ms": ms, "launches_timed": len(ds),
                 "images_per_launch": chunk, "flops_per_launch": fl,
                 "note": "f32 vector/matrix peak (157.3 TFLOP/s); average over actor (6-channel) and critic (4-channel) launches"}
     out["env_error_flags"] = env.error_flags()
@@ -431,8 +451,11 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
         per_launch = ag[0].k13_particle_steps[-len(ds):]                 # one count per launch, in launch order (as the event pairs)
         fl = 2.0 * 12180 * sum(per_launch) / len(per_launch)              # mean FLOP per launch; achieved = total FLOP / total time
         tf = fl / (ms * 1e-3) / 1e12
+        t13, src13 = unit_traffic("rs_pfgru_train_kernel")
         out["roofline_pfgru_train"] = {"bound": "mfma", "kernel": "rs_pfgru_train_kernel (K13)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                                       "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                       "traffic": None if t13 is None else t13 * sum(per_launch) / len(per_launch), "traffic_source": src13,
+                                       "avg_launch_ms": ms,
                                        "launches_timed": len(ds), "particle_steps_per_launch": sum(per_launch) / len(per_launch),
                                        "flops_per_launch": fl,
                                        "note": "f32 vector/matrix peak (157.3 TFLOP/s); the products run as scalar-weight FMAs on the VALU "

@@ -8,7 +8,7 @@ rm -rf $OUT && mkdir -p $OUT
 cd $R
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 scripts/prof_r3_kernels.py > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 scripts/prof_r3_kernels.py > $OUT/write.log 2>&1
-python3 scripts/pmc_traffic.py $OUT/fetch $OUT/write $OUT/r03_pmc_traffic_kernels.json > $OUT/summary.txt 2>&1
+python3 scripts/pmc_traffic.py $OUT/fetch $OUT/write $OUT/r03_pmc_traffic.json $OUT/fetch.log > $OUT/summary.txt 2>&1
 tail -3 $OUT/fetch.log
 cat $OUT/summary.txt
 # keep only the small files

@@ -16,6 +16,12 @@ from radiation_ppo_amd.pfgru import PredictorBank
 from radiation_ppo_amd.ppo import FusedCollector, VecAgentPPO
 from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
 
+# the config-2 kernels first (K7 grad passes, K6 rollout, K4 GAE, K1 at 4096 and 2^20 envs): scripts/prof_update.py as a module
+sys.argv = [sys.argv[0], "3"]
+import runpy
+runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "prof_update.py"), run_name="prof_update")
+torch.cuda.empty_cache()
+
 lib = _lib.load()
 alg = {}
 SEED = 289714752
