@@ -55,8 +55,8 @@ PPO_GRAD_FLOPS_PER_SAMPLE = 58240
 # CNN trunk (conv3x3(Cin->8)-ReLU-pool-conv3x3(8->16)-ReLU) multiply-adds per 27x27 image, zero-padded borders counted:
 #   forward: conv1 729*9*4*8 over the 4 DENSE planes (+ 2*9*8 stamp adds for the actor's two one-hot channels, round 3: those channels
 #   are no longer convolved) + conv2 169*9*8*16;  backward (weight gradients + dP1): dW2 + dP1 = 2 * conv2, dW1 = conv1 / 4 (only the
-#   arg-max pixel of each pool window carries gradient) (+ 2*72 gathers).  Actor 384 768 MAC forward (round 2 counted 489 744 for six
-#   dense channels), critic 384 624.
+#   arg-max pixel of each pool window carries gradient) (+ 2*72 gathers).  Actor 404 784 MAC forward (round 2 counted 509 616 for six
+#   dense channels), critic 404 640.
 def cnn_trunk_flops(cin: int, backward: bool) -> float:
     c1, c2 = 729 * 9 * 4 * 8 + (144 if cin == 6 else 0), 169 * 9 * 8 * 16
     return 2.0 * ((2 * c2 + c1 / 4) if backward else (c1 + c2))
