@@ -316,7 +316,8 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
  *   h, p      [A][N][40][24] particles, [A][N][40] log weights; read; written back when carry_hidden != 0 (mask[n] != 0)
  *   base_key  [A][N], episode [N], calls [N]   counters of the draw hash (documented RNG deviation: the reference draws
  *             from torch's global generator)
- *   pred      [N][A][2]    location prediction (scaled coordinates, >= 0: the reference's MLP ends in a ReLU) */
+ *   pred      [N][A][2]    location prediction (scaled coordinates, >= 0: the reference's MLP ends in a ReLU); with a mask only the
+ *             masked envs' rows are written (the bootstrap round of the collectors, train.py:462-480: the others are not evaluated) */
 #define RS_PFGRU_PARTICLES 40
 #define RS_PFGRU_HIDDEN 24
 #define RS_PFGRU_WEIGHT_FLOATS 3472

@@ -119,6 +119,9 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     if (wv >= (long long)a_.A * a_.N) return;                       // whole waves only: no barrier below
     const int own = __builtin_amdgcn_readfirstlane((int)(wv / a_.N));
     const int n = __builtin_amdgcn_readfirstlane((int)(wv - (long long)own * a_.N));
+    // a masked round (the collectors' bootstrap predictions, train.py:462-480) only counts for the masked envs: the others' rows are
+    // discarded by the caller, so their waves leave at once (a bootstrap round costs the few envs that time out, not all of them)
+    if (a_.mask != nullptr && a_.mask[n] == 0) return;
     unsigned char* base = smem + (size_t)wid * PF_LDS_WAVE;
     float* tile = reinterpret_cast<float*>(base);                   // [P][PF_ROW]
     double* cdf = reinterpret_cast<double*>(base + PF_P * PF_ROW * 4);
