@@ -351,16 +351,16 @@ int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* 
  *   obs [L][E][11] (columns 0..2 used), target [L][E][2], bp [L][E], lens [E] (1..L; steps beyond are never touched), w_ep [E]
  *   h0 / eps / u  the draws of rs_pfgru_draws; u may be NULL: idx[] is then INPUT -- the resampling indices to take (the ones
  *                 torch.multinomial returned in a recorded run of the reference, tests/golden/rada2c_core.npz)
- *   hs [L][E][40][24], ps [L][E][40]  scratch (the resampled particle sets), idx [L][E][40] the resampling indices taken (output
- *                 when u is given)
+ *   hs [L][E][40][24], ps [L][E][40], gates [L][E][40][96]  scratch (the resampled particle sets; the forward walk's gates z | r | n |
+ *                 eps * softplus'(var), reloaded by the backward walk), idx [L][E][40] the resampling indices taken (output when u is given)
  *   loss [E] = w_ep[e] * total_e;  grads [E][RS_PFGRU_TRAIN_GRAD_FLOATS] = the episode's gradient slab:
  *   d[fc_z | fc_r] [48][28] (column 27 = bias) | d fc_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28];
  *   the caller sums the slabs over the episodes. */
 #define RS_PFGRU_TRAIN_WEIGHT_FLOATS 3680
 #define RS_PFGRU_TRAIN_GRAD_FLOATS 3376
 int rs_pfgru_train(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
-                   const float* h0, const float* eps, const double* u, float* hs, float* ps, int32_t* idx, float* loss, float* grads,
-                   int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
+                   const float* h0, const float* eps, const double* u, float* hs, float* ps, float* gates, int32_t* idx, float* loss,
+                   float* grads, int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
                    rs_stream_t stream);
 
 /* ---- RAD-A2C GRU recurrence -----------------------------------------------------------------

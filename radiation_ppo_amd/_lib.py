@@ -102,7 +102,7 @@ SYMBOLS = [
     ("rs_pfgru_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                  C.c_void_p]),
     ("rs_pfgru_draws", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("rs_pfgru_train", C.c_int, [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    ("rs_pfgru_train", C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("rs_rnn_policy_step", C.c_int, [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
     ("rs_welford_update", C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_welford_reset", C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p]),

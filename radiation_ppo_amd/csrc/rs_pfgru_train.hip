@@ -8,8 +8,9 @@
 // resampling :1466-1515, reparameterize :1517-1530, as in K11 (rs_pfgru.hip).
 //
 // Mapping: one wave per episode, one particle per lane (40 of 64; lane 40 carries the weighted-mean "particle" through hid_obs).
-// The wave first runs the episode forward, storing every step's resampled particle set (the only saved state: 3.9 KB per step),
-// then walks it backwards: each step's gates are recomputed from the stored input state, the loss terms of the step are formed
+// The wave first runs the episode forward, storing every step's resampled particle set (3.9 KB per step) and the step's gates
+// z, r, n and eps * softplus'(var) (15 KB per step; round 3 -- round 2 recomputed them from the stored input state, 21 % of the kernel),
+// then walks it backwards: each step's gates are reloaded, the loss terms of the step are formed
 // and differentiated in registers, and the gradient flows to the previous step's particles through the resampling gather (an
 // LDS scatter-add) and the gates.  The small matrix products use wave-uniform weights through the scalar unit (as K11 / K12);
 // the weight gradients are sums over particles of outer products: the per-particle factors are staged transposed in LDS and
@@ -22,6 +23,19 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+
+// Diagnostic build only (-DRS_K13_STAMPS, scripts/k13_stamps.py): s_memtime stamps at the phase boundaries of a step, summed per wave
+// and added to a device table at the end of the episode.  Read the SHARES (the stamps serialise what the product kernel overlaps).
+#ifdef RS_K13_STAMPS
+__device__ unsigned long long rs_k13_cyc[16];
+#define K13_DECL unsigned long long k13_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long k13_t = __builtin_amdgcn_s_memtime();
+#define K13_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long k13_n = __builtin_amdgcn_s_memtime(); k13_acc[i] += k13_n - k13_t; k13_t = k13_n; __builtin_amdgcn_sched_barrier(0); }
+#define K13_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 12; ++q) atomicAdd(&rs_k13_cyc[q], k13_acc[q]); }
+#else
+#define K13_DECL
+#define K13_STAMP(i)
+#define K13_FLUSH
+#endif
 
 namespace {
 
@@ -127,6 +141,10 @@ __device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
     }
 }
 
+// value of lane L (a constant) in every lane: v_readlane_b32 (one instruction into an SGPR) instead of __shfl's LDS permute
+template <int L>
+__device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 
 // gates and candidate state of one particle: z, r, n, es = eps * d softplus(var) / d var, h1 = (1 - z) n + z h0, lg = fc_obs([h1, x])
@@ -171,6 +189,7 @@ struct TrArgs {
     const double* u;          // [L][E][P]  resampling uniforms; NULL: idx[] holds the indices to take (recorded draws)
     float* hs;                // [L][E][P][H] scratch: resampled particles after every step
     float* ps;                // [L][E][P]    scratch: their log weights
+    float* gates;             // [L][E][P][4 H] scratch: z | r | n | eps * softplus'(var) of the forward walk (the backward walk reloads them)
     int32_t* idx;             // [L][E][P]    resampling indices (output; constants of the backward pass)
     float* loss;              // [E]
     float* grads;             // [E][RS_PFGRU_TRAIN_GRAD_FLOATS]
@@ -182,7 +201,8 @@ constexpr int ROW = H + 1;                 // 25: odd stride
 constexpr int TILE_F = 44 * ROW;           // [44][25] particle rows (gather / scatter-add / column sums)
 constexpr int SP = 45;                     // staging row stride: 44 particle columns + 1
 constexpr int DT_F = 48 * SP, IT_F = 32 * SP;
-constexpr int LDS_FLOATS = TILE_F + 2 * P /* cdf (f64) */ + 64 + DT_F + IT_F;
+constexpr int PRE_F = P * 4 * H;           // the next backward step's gates, fetched by LDS-DMA while the current step computes (15 KB)
+constexpr int LDS_FLOATS = TILE_F + 2 * P /* cdf (f64) */ + 64 + DT_F + IT_F + PRE_F;
 
 // acc[ti][tj] += D^T I over the particles: DT [16 TI][SP] (row = output unit, column = particle), IT [16 TJ][SP]
 template <int TI, int TJ>
@@ -225,10 +245,12 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     float* vec = smem + TILE_F + 2 * P;                              // [64]
     float* DT = vec + 64;                                            // [48][SP]
     float* IT = DT + DT_F;                                           // [32][SP]
+    float* pre = IT + IT_F;                                          // [P][4 H] gates of one step, flat as in HBM
     for (int i = lane; i < DT_F + IT_F; i += 64) DT[i] = 0.0f;       // rows 28..31 of IT stay zero for the whole kernel
 
     const bool act = lane < P;
     const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
+    K13_DECL
     // the weight pointer is laundered once per time step and again before every transposed product (wptr): the weights are loop
     // invariant and the forward and transposed products read the same rows -- LICM / GVN would otherwise hoist or keep thousands of
     // scalar loads and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
@@ -263,6 +285,19 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             load_x(t, x);
             load24(a_.eps + te * PH + (size_t)pl * H, eps);
             pf_cell(W, h0, x, eps, z, r, n, es, h1, lg);
+            if (act) {
+                // what the backward walk needs of this step besides the particle sets: 384 B per particle instead of recomputing both
+                // gate products and their transcendentals (phase stamps: the recomputation was 21 % of the kernel)
+                float4* gw = reinterpret_cast<float4*>(a_.gates + (te * P + lane) * (size_t)(4 * H));
+#pragma unroll
+                for (int u = 0; u < H; u += 4) {
+                    gw[u / 4] = make_float4(z[u], z[u + 1], z[u + 2], z[u + 3]);
+                    gw[6 + u / 4] = make_float4(r[u], r[u + 1], r[u + 2], r[u + 3]);
+                    gw[12 + u / 4] = make_float4(n[u], n[u + 1], n[u + 2], n[u + 3]);
+                    gw[18 + u / 4] = make_float4(es[u], es[u + 1], es[u + 2], es[u + 3]);
+                }
+            }
+            K13_STAMP(0)                                             // forward: loads + cell
             lg += p0;
             const float mx = wave_max(act ? lg : -INFINITY);
             const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
@@ -302,6 +337,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
                 a_.ps[te * P + lane] = p0;
                 a_.idx[te * P + lane] = idx;
             }
+            K13_STAMP(1)                                             // forward: softmax, resampling, stores
         }
     }
 
@@ -331,12 +367,27 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     const bool stage = lane < 44;                                    // the lanes that own a staging column
     const bool act41 = lane <= P;                                    // particles + the mean "particle" in lane 40
 
+    // a step's gates (40 x 96 floats, contiguous in HBM) -> `pre`, 15 global_load_lds_dwordx4: issued for step t - 1 as soon as step
+    // t's gates are in registers, so the 15 KB arrive under the ~90 k cycles of the step instead of in front of it
+    auto dma_gates = [&](int t) {
+        const float* src = a_.gates + ((size_t)t * E + e) * (size_t)(P * 4 * H);
+#pragma unroll
+        for (int i = 0; i < PRE_F / 256; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(pre + i * 256), 16, 0, 0);
+    };
+    if (len > 0) dma_gates(len - 1);
+
     for (int t = len - 1; t >= 0; --t) {
         const cmem_t W = wptr();
         const size_t te = (size_t)t * E + e;
         float h0[H], x[IN], z[H], r[H], n[H], es[H], h1[H], lg, p0;
+        // everything else the step reads from HBM is requested here, in one round trip
+        const int idx = a_.idx[te * P + pl];
+        float h1r[H];
+        load24(a_.hs + te * PH + (size_t)pl * H, h1r);
+        const float ps_t = a_.ps[te * P + pl];
         {
-            float eps[H];
             if (t > 0) {
                 load24(a_.hs + (te - E) * PH + (size_t)pl * H, h0);
                 p0 = a_.ps[(te - E) * P + pl];
@@ -345,17 +396,38 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
                 p0 = -3.6888794541139363f;
             }
             load_x(t, x);
-            load24(a_.eps + te * PH + (size_t)pl * H, eps);
-            pf_cell(W, h0, x, eps, z, r, n, es, h1, lg);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of this step's gates (and the loads above) have landed
+            __builtin_amdgcn_wave_barrier();
+            {
+                const float4* gr = reinterpret_cast<const float4*>(pre + pl * (4 * H));
+#pragma unroll
+                for (int u = 0; u < H; u += 4) {
+                    const float4 a = gr[u / 4], b = gr[6 + u / 4], c = gr[12 + u / 4], d = gr[18 + u / 4];
+                    z[u] = a.x; z[u + 1] = a.y; z[u + 2] = a.z; z[u + 3] = a.w;
+                    r[u] = b.x; r[u + 1] = b.y; r[u + 2] = b.z; r[u + 3] = b.w;
+                    n[u] = c.x; n[u + 1] = c.y; n[u + 2] = c.z; n[u + 3] = c.w;
+                    es[u] = d.x; es[u + 1] = d.y; es[u + 2] = d.z; es[u + 3] = d.w;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the gates are in registers: `pre` may be overwritten
+            __builtin_amdgcn_wave_barrier();
+            if (t > 0) dma_gates(t - 1);
+            // h1 and the observation logit exactly as pf_cell forms them
+            lg = W[T_O + 27];
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                h1[u] = (1.0f - z[u]) * n[u] + z[u] * h0[u];
+                lg = fmaf(W[T_O + u], h1[u], lg);
+            }
+#pragma unroll
+            for (int k = 0; k < IN; ++k) lg = fmaf(W[T_O + H + k], x[k], lg);
         }
+        K13_STAMP(2)                                                 // backward: loads of the step's gates, h1 and logit
         lg += p0;
         const float mx = wave_max(act ? lg : -INFINITY);
         const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
         const float p1 = (lg - mx) - logf(se);
-        const int idx = a_.idx[te * P + pl];
-        float h1r[H];
-        load24(a_.hs + te * PH + (size_t)pl * H, h1r);
-        const float pi = act ? expf(a_.ps[te * P + pl]) : 0.0f;
+        const float pi = act ? expf(ps_t) : 0.0f;
 
         // ---- weighted mean of the resampled particles -> vec[0..23]
 #pragma unroll
@@ -369,6 +441,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             vec[lane] = mean;
             __builtin_amdgcn_wave_barrier();
         }
+        K13_STAMP(3)                                                 // log-softmax, loads of the resampled set, weighted mean
         // ---- hid_obs on every particle (lanes 0..39) and on the mean (lane 40)
         float v[H];
 #pragma unroll
@@ -403,7 +476,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
                 gpart += l1w * 10.0f * sg * bpt * e1 / (P * y1);
                 l1ps += -logf(y1);
             }
-            const float dm = __shfl(d, P);                           // the mean prediction's error (lane 40)
+            const float dm = lane_bcast<P>(d);                           // the mean prediction's error (lane 40)
             const float sgm = dm > 0.0f ? 1.0f : (dm < 0.0f ? -1.0f : 0.0f);
             l2s += dm * dm * bpt;
             l1s += fabsf(dm) * bpt;
@@ -411,6 +484,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             const float dout = act ? G * elbo * gpart * inv_nel : (lane == P ? G * gmean : 0.0f);
             dop[c] = out[c] > 0.0f ? dout : 0.0f;
         }
+        K13_STAMP(4)                                                 // hid_obs forward + loss terms
         // ---- hid_obs backwards: thin gradients in per-lane accumulators, hid_obs[0]'s on the matrix cores
         float du[H];
 #pragma unroll
@@ -437,11 +511,12 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2>(DT, IT, accW2, lane);
         __builtin_amdgcn_wave_barrier();
+        K13_STAMP(5)                                                 // hid_obs backward: transposed product, two outer products
         // ---- gradient at the resampled particles and their log weights
         float dot = 0.0f;
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const float dmean = __shfl(dv[k], P);
+            const float dmean = lane_bcast<P>(dv[k]);
             dh[k] = dh[k] + dv[k] + pi * dmean;                      // dL / d h1r
             dot = fmaf(dmean, h1r[k], dot);
         }
@@ -469,6 +544,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         const float dlp = dp1 - expf(p1) * wave_sum(dp1);            // through p1 = lp - logsumexp(lp); also d / d p0
         dp = dlp;
+        K13_STAMP(6)                                                 // resampling backwards: scatter-add, softmax derivatives
         // ---- fc_obs: d fc_obs = sum over particles of dlp (x) [h1 | x | 1] (row 0 of a tile, as d hid_obs[2] above)
 #pragma unroll
         for (int k = 0; k < H; ++k) dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
@@ -483,6 +559,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2>(DT, IT, accO, lane);
         __builtin_amdgcn_wave_barrier();
+        K13_STAMP(7)                                                 // fc_obs outer product
         // ---- h1 = (1 - z) n + z h0, n = tanh(mu + eps softplus(var))
         float dan[48], dz[H];
 #pragma unroll
@@ -505,10 +582,12 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<3, 2>(DT, IT, accN, lane);
         __builtin_amdgcn_wave_barrier();
+        K13_STAMP(8)                                                 // d candidate, staging, outer product N
         float drh[H];
 #pragma unroll
         for (int o = 0; o < H; ++o) drh[o] = 0.0f;
         mvt<H, 48>(wptr() + T_N, [&](int o) -> float { return dan[o]; }, drh);
+        K13_STAMP(9)                                                 // transposed product N
         // ---- z, r = sigmoid(W_zr [h0, x] + b)
 #pragma unroll
         for (int u = 0; u < H; ++u) {
@@ -526,8 +605,11 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         outer_acc<3, 2>(DT, IT, accZR, lane);
         __builtin_amdgcn_wave_barrier();
+        K13_STAMP(10)                                                // d gates, staging, outer product ZR
         mvt<H, 48>(wptr() + T_ZR, [&](int o) -> float { return dan[o]; }, dh);                  // dL / d (h1r of step t - 1), particle by particle
+        K13_STAMP(11)                                                // transposed product ZR
     }
+    K13_FLUSH
 
     // ------------------------------------------------------------------------------------------ the episode's slab
     float* g = a_.grads + (size_t)e * RS_PFGRU_TRAIN_GRAD_FLOATS;
@@ -548,14 +630,22 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
 
 extern "C" {
 
+#ifdef RS_K13_STAMPS
+int rs_debug_k13_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {0};
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(rs_k13_cyc), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rs_k13_cyc), sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int rs_pfgru_train(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
-                   const float* h0, const float* eps, const double* u, float* hs, float* ps, int32_t* idx, float* loss, float* grads,
-                   int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
+                   const float* h0, const float* eps, const double* u, float* hs, float* ps, float* gates, int32_t* idx, float* loss,
+                   float* grads, int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
                    rs_stream_t stream) {
-    if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !hs || !ps || !idx || !loss || !grads || steps < 1 ||
+    if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !hs || !ps || !gates || !idx || !loss || !grads || steps < 1 ||
         episodes < 1)
         return RS_ERR_INVALID_ARG;
-    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, idx, loss, grads, steps, episodes, (float)alpha,
+    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
              (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
     hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;

@@ -641,10 +641,14 @@ class RNNAgentPPO:
         self.k13_particle_steps.append(int(sum(B.chunk(sl).lens_host)) * 40)
         if d._u is None:                                                           # recorded draws: idx is the kernel's INPUT
             idx.copy_(d._idx32)
+        # the forward walk's gates (384 B per particle-step): one scratch buffer shared by all chunks and iterations (stream ordered)
+        need = L * E * 40 * 96
+        if getattr(self, "_k13_gates", None) is None or self._k13_gates.numel() < need:
+            self._k13_gates = torch.empty(need, dtype=torch.float32, device=dev)
         with _lib.timed("rs_pfgru_train"):
             _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
                                                   d._pf.data_ptr(), d._eps.data_ptr(), None if d._u is None else d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
-                                                  idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
+                                                  self._k13_gates.data_ptr(), idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
                                                   float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
         return loss.double().sum(), slab.sum(dim=0), idx
