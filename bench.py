@@ -445,11 +445,12 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
     ds = _ms(ev.get("rs_pfgru_train", []))
     if ds:
-        # K13: 12 180 multiply-adds per particle-step (forward 2 619, the same recomputed in the backward walk, hid_obs forward + backward
-        # 1 248, transposed products 2 328, weight-gradient outer products 3 366), 40 particles per episode-step
+        # K13: 9 561 multiply-adds per particle-step (forward cell 2 619, hid_obs forward + backward 1 248, transposed products 2 328,
+        # weight-gradient outer products 3 366), 40 particles per episode-step.  Round 2 counted 12 180: it
+        # included the forward cell RECOMPUTED in the backward walk, which round 3 replaced by stored gates -- not algorithmic work.
         ms = sum(ds) / len(ds)
         per_launch = ag[0].k13_particle_steps[-len(ds):]                 # one count per launch, in launch order (as the event pairs)
-        fl = 2.0 * 12180 * sum(per_launch) / len(per_launch)              # mean FLOP per launch; achieved = total FLOP / total time
+        fl = 2.0 * 9561 * sum(per_launch) / len(per_launch)               # mean FLOP per launch; achieved = total FLOP / total time
         tf = fl / (ms * 1e-3) / 1e12
         t13, src13 = unit_traffic("rs_pfgru_train_kernel")
         out["roofline_pfgru_train"] = {"bound": "mfma", "kernel": "rs_pfgru_train_kernel (K13)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,

@@ -91,6 +91,7 @@ col.collect()
 col.update()
 torch.cuda.synchronize()
 ps = ag[0].k13_particle_steps[-1]
-# per particle-step: forward reads eps 96 B, writes the resampled particle 96 + 4 + 4 B; backward reads two particle sets + eps + idx: ~300 B
-alg["rs_pfgru_train_kernel"] = ps * (96 + 104 + 2 * 100 + 96 + 4)
+# per particle-step: forward reads eps 96 B, writes the resampled particle 96 + 4 + 4 B and the gates 384 B; backward reads the gates 384 B,
+# two particle sets 200 B and the index 4 B
+alg["rs_pfgru_train_kernel"] = ps * (96 + 104 + 384 + 384 + 2 * 100 + 4)
 print(json.dumps({"algorithmic_bytes_per_launch": alg, "k13_particle_steps": ps}))
