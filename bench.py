@@ -91,38 +91,51 @@ def _py_worker(args):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline_obstacles(obst: int, agents: int, seconds: float = 5.0):
-    """The configuration's own CPU figure: the Python oracle (the port closest to the reference's Python env.step; obstacle geometry
-    = the exact-lattice restatement of the visilibity calls) on the host cores, the config's obstruction_count and agent count, uniform
-    random actions, a fresh layout every 480 steps.  (oracle/radsearch_oracle.c restates the obstacle-free env only.)"""
-    import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_py_worker, [(w, 8, seconds, obst, agents) for w in range(cores)])
-    one = res[0]
-    return {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env steps/s", "cores": cores, "kind": "port",
-            "single_core_value": one[0] / one[1],
-            "sample": f"{cores} procs x 8 envs, obstruction_count={obst}, {agents} agent(s), uniform random actions, ~{seconds:.0f} s each, "
-                      "oracle/radsearch_oracle.py (pure Python); env step + reset only, no policy"}
-
-
 def _c_lib():
     import ctypes as C
-    so = os.path.join(ROOT, "oracle", "_build", "librs_oracle.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    lib = C.CDLL(so)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)          # a no-op when the library is current
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "librs_oracle.so"))
     lib.rso_bench.restype = C.c_long
     lib.rso_bench.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_long, C.c_int]
+    lib.rso_bench2.restype = C.c_long
+    lib.rso_bench2.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
     return lib
 
 
 def _c_worker(args):
-    wid, n_envs, target = args
+    wid, n_envs, target = args[:3]
+    obst, agents = (args[3], args[4]) if len(args) > 3 else (0, 1)
     lib = _c_lib()
     t0 = time.perf_counter()
-    n = lib.rso_bench(SEED, wid * n_envs, n_envs, target, L_EPISODE)
-    return abs(n), time.perf_counter() - t0
+    if obst == 0 and agents == 1:
+        n = lib.rso_bench(SEED, wid * n_envs, n_envs, target, L_EPISODE)
+    else:
+        n = lib.rso_bench2(SEED, wid * n_envs, n_envs, target, L_EPISODE, T_EPOCH, obst, agents)
+    if n < 0:
+        raise RuntimeError("the C oracle's bench loop raised an environment error flag")
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_obstacles(obst: int, agents: int, seconds: float = 5.0):
+    """The configuration's own CPU figure: the C restatement of the env with obstructions (oracle/radsearch_oracle.c, pinned event by
+    event to the Python oracle by tests/test_oracle_c.py; obstacle geometry = the exact-lattice restatement of the visilibity calls) on
+    the host cores, the config's obstruction_count and agent count, uniform random actions, a fresh layout every 480 lock-steps.  The
+    pure-Python oracle (the port closest to the reference's Python env.step) is timed beside it on the same cores."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    probe = _c_worker((0, 8, 100_000, obst, agents))
+    rate = probe[0] / probe[1]
+    target = max(int(rate * seconds), 10_000)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_c_worker, [(w, 8, target, obst, agents) for w in range(cores)])
+        py = pool.map(_py_worker, [(w, 8, min(seconds, 4.0), obst, agents) for w in range(cores)])
+    return {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env steps/s", "cores": cores, "kind": "port",
+            "single_core_value": rate,
+            "python_port_all_cores_value": sum(r[0] for r in py) / max(r[1] for r in py),
+            "python_port_single_core_value": py[0][0] / py[0][1],
+            "sample": f"{cores} procs x 8 envs, obstruction_count={obst}, {agents} agent(s), uniform random actions, {target} env steps "
+                      f"(~{seconds:.0f} s) each, oracle/radsearch_oracle.c (-O2, scalar); env step + reset only, no policy; python port: "
+                      f"oracle/radsearch_oracle.py, same envs, ~{min(seconds, 4.0):.0f} s per process"}
 
 
 def cpu_baseline(seconds: float = 8.0):
