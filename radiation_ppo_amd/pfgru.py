@@ -299,6 +299,10 @@ class PredictorBank:
         cdf = torch.cumsum((al * torch.exp(p1) + (1 - al) / P).double(), dim=2)
         cdf = cdf / cdf[..., -1:]
         idx = torch.searchsorted(cdf.view(A * N, P), ru.view(A * N, P).contiguous(), right=True).clamp_(max=P - 1).view(A, N, P)
+        if getattr(self, "record_margin", False):
+            # test hook: how close each (owner, env) came to another resampling index -- the smallest distance between one of its
+            # uniforms and a CDF value.  A float32 rounding difference in the weights can only move an index where this is ~1e-7.
+            self.last_margin = (cdf.unsqueeze(2) - ru.unsqueeze(3)).abs().amin(dim=(2, 3))                   # [A, N]
         h1 = torch.gather(h1, 2, idx.unsqueeze(-1).expand(A, N, P, H))
         pn = torch.exp(torch.gather(p1, 2, idx))
         pn = torch.log(pn / (al * pn + (1 - al) / P))

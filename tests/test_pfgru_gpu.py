@@ -1,14 +1,16 @@
 """K11 (csrc/rs_pfgru.hip: rs_pfgru_step / rs_pfgru_reset through the C ABI) against the torch composition of the same
 arithmetic (PredictorBank(impl="torch")), which tests/test_pfgru_golden.py pins to the reference's PFGRUCell with recorded
-draws.  float32 with different summation orders: rtol 1e-4 / atol 2e-5; the resampling indices are discrete (inverse CDF
-against a hashed uniform), so a 1e-7 difference in a weight can move an index once in ~1e5 rows -- at most 0.2 % of the rows
-may differ beyond the tolerance."""
+draws (tests/test_rows_f_golden_gpu.py feeds the kernel the reference's recorded draws directly).  float32 with different
+summation orders: rtol 1e-4 / atol 2e-5.  The resampling indices are discrete (inverse CDF against a hashed uniform): a
+rounding difference in a weight can move an index only where a uniform lies within ~1e-6 of a CDF value.  Those rows are
+COUNTED, not waved through: every (owner, env) row that differs beyond the tolerance must have such a near-tie (the torch
+composition reports the distance, PredictorBank.last_margin), and there may be no more of them than near-ties exist."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL, MAX_BAD = 1e-4, 2e-5, 0.002
+RTOL, ATOL, TIE = 1e-4, 2e-5, 2e-6
 
 
 def _banks(N, A, carry, seed=7, base=96):
@@ -21,9 +23,10 @@ def _banks(N, A, carry, seed=7, base=96):
     return hip, ref
 
 
-def _close_rows(x, y):
+def _bad_rows(x, y):
+    """[A, N, ...] -> [A, N] bool: the (owner, env) rows that differ beyond the tolerance"""
     bad = ~torch.isclose(x, y, rtol=RTOL, atol=ATOL)
-    return bad.reshape(bad.shape[0], -1).any(dim=1).float().mean().item()
+    return bad.reshape(bad.shape[0], bad.shape[1], -1).any(dim=2)
 
 
 def test_reset_draws_are_bit_exact_and_masked():
@@ -43,9 +46,10 @@ def test_reset_draws_are_bit_exact_and_masked():
 def test_step_matches_torch_composition(carry):
     N, A = 1024, 4
     hip, ref = _banks(N, A, carry)
+    ref.record_margin = True
     hip.reset(); ref.reset()
     g = torch.Generator(device="cuda").manual_seed(11)
-    worst = 0.0
+    moved = ties = 0
     for t in range(6):
         obs = torch.rand(N, A, 11, device="cuda", generator=g)
         obs[..., 0] = torch.randint(0, 4000, (N, A), device="cuda", generator=g).float() / 100.0      # standardised readings vary widely
@@ -53,25 +57,24 @@ def test_step_matches_torch_composition(carry):
         mask = None if t % 2 == 0 else (torch.rand(N, device="cuda", generator=g) < 0.6)
         ph, pr = hip.predict(obs, mask), ref.predict(obs, mask)
         assert ph.shape == (N, A, 2) and torch.isfinite(ph).all() and float(ph.min()) >= 0.0
-        if mask is not None:                                       # a masked round predicts for the masked envs only (the others' waves
-            ph, pr = ph[mask], pr[mask]                            # leave at once: their rows keep whatever the last round wrote)
-        frac = _close_rows(ph.reshape(-1, 2), pr.reshape(-1, 2))
-        worst = max(worst, frac)
-        assert frac <= MAX_BAD, (t, frac)
+        counted = torch.ones(N, dtype=torch.bool, device="cuda") if mask is None else mask           # a masked round predicts for the
+        near_tie = ref.last_margin < TIE                                                              # masked envs only (the others'
+        bad = _bad_rows(ph.permute(1, 0, 2), pr.permute(1, 0, 2)) & counted.view(1, N)                # waves leave at once)
         if carry:
             # carried particle sets: compare, then continue both from the SAME state so that one moved index does not compound
-            fh = _close_rows(hip.h.reshape(A * N, -1), ref.h.reshape(A * N, -1))
-            fp = _close_rows(hip.p.reshape(A * N, -1), ref.p.reshape(A * N, -1))
-            assert fh <= MAX_BAD and fp <= MAX_BAD, (t, fh, fp)
+            bad |= (_bad_rows(hip.h, ref.h) | _bad_rows(hip.p.unsqueeze(-1), ref.p.unsqueeze(-1))) & counted.view(1, N)
             ref.h, ref.p = hip.h.clone(), hip.p.clone()
         else:
             assert torch.equal(hip.h, ref.h)                       # without carry the step never writes the particle sets
+        assert not bool((bad & ~near_tie).any()), (t, int((bad & ~near_tie).sum()))                  # no difference without a near-tie
+        moved += int(bad.sum()); ties += int((near_tie & counted.view(1, N)).sum())
         assert torch.equal(hip.calls, ref.calls)
         if t == 3:
             cut = torch.rand(N, device="cuda", generator=g) < 0.25
             hip.reset(mask=cut); ref.reset(mask=cut)
             assert torch.equal(hip.h[:, cut], ref.h[:, cut])
-    print("worst mismatching-row fraction", worst)
+    print(f"rows with a moved resampling index: {moved} of {ties} near-ties (|u - cdf| < {TIE}) in {6 * A * N} rows")
+    assert moved <= ties
 
 
 def test_predictions_do_not_depend_on_sharding():
