@@ -4,8 +4,8 @@
 // forward and backward, straight from the resident heat maps.  The channel counts (6/4 -> 8 -> 16) are far too
 // small for an implicit-GEMM library convolution (MIOpen spends minutes tuning and then runs at ~5 % of the f32
 // peak on these shapes), so the trunk is written directly:
-//   * one image per 192-thread workgroup at a time, the whole image in LDS (zero-padded planes), workgroups
-//     stride over the batch (persistent grid);
+//   * whole images in LDS (zero-padded planes), workgroups stride over the batch (persistent grid): forward three images per
+//     512-thread workgroup at a time (507 lanes own a pooled cell), backward one image per 256-thread workgroup;
 //   * the input stack is never materialised in HBM: the 4 shared maps of a sample are read once (11.7 KB).  Of the actor's six
 //     channels (CNNBase.get_map_stack, RADTEAM_core.py:1791-1836) only these four are dense; the owner's prediction and location
 //     maps are ONE-HOT and `others = combined - location`, so conv1 runs over the 4 dense planes (`combined` with the weights of
@@ -34,10 +34,6 @@ namespace {
 #endif
 #ifndef CNN_BWD_PREFETCH
 #define CNN_BWD_PREFETCH 1
-#endif
-constexpr int CNN_NT = 192;                 // forward: 3 waves per workgroup; 169 threads own a pooled cell / pixel
-#ifndef CNN_FWD_WAVES
-#define CNN_FWD_WAVES 3
 #endif
 #ifndef CNN_NTB
 #define CNN_NTB 256
@@ -109,8 +105,8 @@ struct CnnIn {
 // decomposed every element index with four divisions by constants, 19 % of K9's instructions.
 template <int NT>
 struct CnnFetch {
-    static constexpr int G = NT / MAPW;                                 // 7 (NT = 192) / 9 (NT = 256)
-    static constexpr int PER_THREAD = (4 * MAPW + G - 1) / G;           // 16 / 12 rows per thread
+    static constexpr int G = NT / MAPW;                                 // 9 (NT = 256, the backward kernel)
+    static constexpr int PER_THREAD = (4 * MAPW + G - 1) / G;           // 12 rows per thread
     float m[PER_THREAD];
     int loc, pc;
 };
@@ -150,29 +146,78 @@ __device__ __forceinline__ void cnn_stage(const CnnFetch<NT>& f, float* xp) {
 // K9 forward: maps -> a2 [S][2704] (post-ReLU conv2 output, torch Flatten order c*169 + y*13 + x), and for
 // training p1 [S][8][169] (pooled activations) + amax [S][8][169] (which pixel of the 2x2 window won, 0..3 in
 // row-major order; first maximum wins like torch's CPU max_pool2d).
+// THREE consecutive images per 512-thread workgroup (round 3): 3 x 169 = 507 of 512 lanes own a pooled cell / pixel (one image per
+// 192 threads left 12 % of the lanes idle in a VALU-bound kernel); the three images' 12 planes are one contiguous block of 324 map
+// rows in HBM = 18 rows for each of the 18 staging groups of 27 threads.
+constexpr int FW_IMG = 3, FW_NT = 512;
+constexpr int FW_G = FW_NT / MAPW;                                  // 18 staging groups
+constexpr int FW_ROWS = FW_IMG * 4 * MAPW;                          // 324 map rows per workgroup round
+constexpr int FW_PER = (FW_ROWS + FW_G - 1) / FW_G;                 // 18 rows per staging thread
+constexpr int FW_OWN = FW_IMG * PC;                                 // 507 owning threads
+
+struct FwFetch {
+    float m[FW_PER];
+    int loc, pc;
+};
+
 template <int CIN>
-__global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
+__device__ __forceinline__ void fw_fetch(const CnnIn& in, long long s0, int img, FwFetch& f) {
+    const long long left = in.S - s0;                               // images left from s0 on (>= 1)
+    const int lim = (int)(left < FW_IMG ? left : FW_IMG) * 4 * MAPC;
+    const float* src = in.maps + (size_t)s0 * 4 * MAPC;
+    const bool active = threadIdx.x < FW_G * MAPW;
+#pragma unroll
+    for (int i = 0; i < FW_PER; ++i) {
+        const int e = threadIdx.x + i * FW_G * MAPW;
+        f.m[i] = (active && e < lim) ? src[e] : 0.0f;
+    }
+    f.loc = -1; f.pc = -1;
+    if (CIN == 6 && img < FW_IMG && s0 + img < in.S) {
+        f.loc = (int)in.cells[(size_t)(s0 + img) * in.A + in.agent];
+        f.pc = (int)in.pcells[(size_t)(s0 + img) * in.A + in.agent];
+    }
+}
+
+__device__ __forceinline__ void fw_stage(const FwFetch& f, float* xp) {
+    const int g = threadIdx.x / MAPW, c = threadIdx.x - g * MAPW;
+    const bool active = g < FW_G;
+    int r = g, dst = (g + 1) * XP_RS + c + 1;                           // map row g of plane 0; the planes of all images are equally strided
+#pragma unroll
+    for (int i = 0; i < FW_PER; ++i) {
+        if (active && g + i * FW_G < FW_ROWS) xp[dst] = f.m[i];
+        r += FW_G; dst += FW_G * XP_RS;
+        if (r >= MAPW) { r -= MAPW; dst += XP_PLANE - MAPW * XP_RS; }  // into the next plane (FW_G < 27: one wrap at most)
+    }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const float* __restrict__ wt, float* __restrict__ a2,
                                                             float* __restrict__ p1g, uint8_t* __restrict__ amax,
                                                             uint16_t* __restrict__ relu_mask) {
     extern __shared__ __align__(16) float smem[];
-    float* xp = smem;                               // [4 dense planes][28][28]
-    float* pp = xp + DP * XP_PLANE;                 // [8][15][15]
-    float* stl = pp + C1 * PP_PLANE;                // [2][9][8] actor: the one-hot channels' weight stamps
+    float* xp = smem;                               // [FW_IMG][4 dense planes][28][28]
+    float* pp = xp + FW_IMG * DP * XP_PLANE;        // [FW_IMG][8][15][15]
+    float* stl = pp + FW_IMG * C1 * PP_PLANE;       // [2][9][8] actor: the one-hot channels' weight stamps
     constexpr int CH0 = (CIN == 6) ? 2 : 0;         // the logical channel of dense plane 0 (actor: `others`, convolved as `combined`)
     const cmem_t w1c = as_cmem(wt + WT_W1(CIN) + CH0 * 9 * C1), b1c = as_cmem(wt + WT_B1(CIN));
     const cmem_t w2c = as_cmem(wt + WT_W2(CIN)), b2c = as_cmem(wt + WT_B2(CIN));
     const int tid = threadIdx.x;
-    for (int e = tid; e < DP * XP_PLANE + C1 * PP_PLANE; e += CNN_NT) smem[e] = 0.0f;      // borders stay zero
+    for (int e = tid; e < FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE); e += FW_NT) smem[e] = 0.0f;      // borders stay zero
     if (CIN == 6 && tid < 2 * 9 * C1) stl[tid] = wt[WT_ST(CIN) + tid];
     __syncthreads();
-    const int py = tid / PW, px = tid - py * PW;
-    const bool own = tid < PC;
-    CnnFetch<CNN_NT> f;
-    if ((long long)blockIdx.x < in.S) cnn_fetch<CIN, CNN_NT>(in, blockIdx.x, f);
-    for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
+    const int img = tid / PC, cell = tid - img * PC;                 // img == FW_IMG: the five threads that own nothing
+    const int py = cell / PW, px = cell - py * PW;
+    const float* xpi = xp + (img < FW_IMG ? img : 0) * DP * XP_PLANE;
+    float* ppi = pp + (img < FW_IMG ? img : 0) * C1 * PP_PLANE;
+    const long long rounds = (in.S + FW_IMG - 1) / FW_IMG;
+    FwFetch f;
+    if ((long long)blockIdx.x < rounds) fw_fetch<CIN>(in, (long long)blockIdx.x * FW_IMG, img, f);
+    for (long long rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+        const long long s = rd * FW_IMG + img;
+        const bool own = tid < FW_OWN && s < in.S;
         const int loc = f.loc, pc = f.pc;
-        cnn_stage<XP_PLANE, CNN_NT>(f, xp);
-        if (s + gridDim.x < in.S) cnn_fetch<CIN, CNN_NT>(in, s + gridDim.x, f);      // next sample: in flight during the compute
+        fw_stage(f, xp);
+        if (rd + gridDim.x < rounds) fw_fetch<CIN>(in, (rd + gridDim.x) * FW_IMG, img, f);      // next round: in flight during the compute
         __syncthreads();
         if (own) {
             // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
@@ -186,8 +231,8 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
                 float win[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float2 a = *reinterpret_cast<const float2*>(&xp[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px]);
-                    const float2 b = *reinterpret_cast<const float2*>(&xp[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px + 2]);
+                    const float2 a = *reinterpret_cast<const float2*>(&xpi[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px]);
+                    const float2 b = *reinterpret_cast<const float2*>(&xpi[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px + 2]);
                     win[r][0] = a.x; win[r][1] = a.y; win[r][2] = b.x; win[r][3] = b.y;
                 }
 #pragma unroll
@@ -215,9 +260,9 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
             }
             if (CIN == 6) {
                 // the one-hot channels: a 1 at input (r, c) adds w[ky][kx] to conv output (r - ky + 1, c - kx + 1); at most four cells
-                // of the image own such a pixel (loc / pc are workgroup-uniform: the range test is two scalar compares)
-                auto stamp = [&](int cell, const float* ws) {
-                    const int r = cell / MAPW, c = cell - r * MAPW;
+                // of an image own such a pixel
+                auto stamp = [&](int at, const float* ws) {
+                    const int r = at / MAPW, c = at - r * MAPW;
                     const int dy = r - 2 * py, dx = c - 2 * px;
                     if (dy >= -1 && dy <= 2 && dx >= -1 && dx <= 2) {
 #pragma unroll
@@ -249,15 +294,15 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
                     const float v = fmaxf(acc[p][co] + bb, 0.0f);
                     if (v > best) { best = v; idx = p; }
                 }
-                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = best;
+                ppi[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = best;
                 pbest[co] = best;
                 pidx[co >> 2] |= (uint32_t)idx << (8 * (co & 3));
             }
             if (p1g) {                  // cell-major rows: 32 B of p1 and 8 B of amax per thread, contiguous across the wave
-                v4f* dst = reinterpret_cast<v4f*>(p1g + ((size_t)s * PC + tid) * C1);
+                v4f* dst = reinterpret_cast<v4f*>(p1g + ((size_t)s * PC + cell) * C1);
                 dst[0] = (v4f){pbest[0], pbest[1], pbest[2], pbest[3]};
                 dst[1] = (v4f){pbest[4], pbest[5], pbest[6], pbest[7]};
-                *reinterpret_cast<uint2*>(amax + ((size_t)s * PC + tid) * C1) = make_uint2(pidx[0], pidx[1]);
+                *reinterpret_cast<uint2*>(amax + ((size_t)s * PC + cell) * C1) = make_uint2(pidx[0], pidx[1]);
             }
         }
         __syncthreads();
@@ -272,7 +317,7 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float v = pp[ci * PP_PLANE + (py + ky) * PP_RS + px + kx];
+                        const float v = ppi[ci * PP_PLANE + (py + ky) * PP_RS + px + kx];
 #pragma unroll
                         for (int q = 0; q < C2; ++q) acc2[q] = __builtin_fmaf(w2c[((ci * 3 + ky) * 3 + kx) * C2 + q], v, acc2[q]);
                     }
@@ -280,10 +325,10 @@ __global__ void __launch_bounds__(CNN_NT, CNN_FWD_WAVES) rs_cnn_fwd_kernel(CnnIn
 #pragma unroll
             for (int co = 0; co < C2; ++co) {
                 const float o = fmaxf(acc2[co] + b2c[co], 0.0f);
-                a2[(size_t)s * FLAT + co * PC + tid] = o;
+                a2[(size_t)s * FLAT + co * PC + cell] = o;
                 live |= (o > 0.0f ? 1u : 0u) << co;
             }
-            if (relu_mask) relu_mask[(size_t)s * PC + tid] = (uint16_t)live;       // what backward needs of a2: its sign
+            if (relu_mask) relu_mask[(size_t)s * PC + cell] = (uint16_t)live;       // what backward needs of a2: its sign
         }
         __syncthreads();
     }
@@ -499,7 +544,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     }
 }
 
-inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(DP * XP_PLANE + C1 * PP_PLANE + 2 * 9 * C1); }
+inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE) + 2 * 9 * C1); }
 inline size_t bwd_lds(int) {
     size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
     size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
@@ -538,9 +583,9 @@ int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t*
     hipStream_t s = (hipStream_t)stream;
     const int cin = agent >= 0 ? 6 : 4;
     hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, s, cin, w1, b1, w2, b2, wscratch);
-    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, CNN_NT, fwd_lds(6), num_samples)), dim3(CNN_NT),
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, FW_NT, fwd_lds(6), (num_samples + FW_IMG - 1) / FW_IMG)), dim3(FW_NT),
                                        fwd_lds(6), s, in, wscratch, a2, p1, amax, relu_mask);
-    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, CNN_NT, fwd_lds(4), num_samples)), dim3(CNN_NT),
+    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, FW_NT, fwd_lds(4), (num_samples + FW_IMG - 1) / FW_IMG)), dim3(FW_NT),
                             fwd_lds(4), s, in, wscratch, a2, p1, amax, relu_mask);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
