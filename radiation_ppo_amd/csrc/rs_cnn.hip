@@ -49,6 +49,7 @@ constexpr int XP_PLANE_B = 28 * 28 + 7;         // backward: ODD plane stride --
                                                 // land in the other 16 LDS banks (see the bank map in rs_cnn_bwd_kernel)
 constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
+constexpr int DP1_SPLIT = 13;                   // backward, dP1: output channels [0, 13) on the pixel threads, [13, 16) on the helper wave (measured: 16 -> 707, 13 -> 672, 12 -> 676, 10 -> 703 us per 32768 images)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 // Weights are read through the scalar unit: a wave-uniform s_load_dwordx8/x16 from the constant address space feeds
@@ -346,11 +347,12 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     float* xp = smem;                               // [4 dense planes][28][28] (plane stride XP_PLANE_B)
     float* pp = xp + DP * XP_PLANE_B;               // [8][15][15]   padded P1
     float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
-    float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate
-    uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbuf + C1 * PC);      // [169][8]
+    float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate: output channels 0..12 of conv2
+    float* gbufb = gbuf + C1 * PC;                  // [8][169]      ... and 13..15 (the helper wave's share)
+    uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbufb + C1 * PC);     // [169][8]
     int* celloff = reinterpret_cast<int*>(ambuf + C1 * PC);           // [169] offset of a cell's 2x2 block inside a padded plane
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id as a scalar
     constexpr int NWAVE = CNN_NT_BWD / 64;
     for (int e = tid; e < DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
     __syncthreads();
@@ -439,29 +441,45 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
             }
         }
 #endif
-        // ---- dP1 = conv2^T(dZ2), gated by the pool's ReLU (P1 > 0)
+        // ---- dP1 = conv2^T(dZ2), gated by the pool's ReLU (P1 > 0).  The sum over the 16 output channels is split between the pixel
+        // threads (waves 0-2: co 0..12, 117 taps each) and the helper wave (co 13..15 for up to three pixels per lane, 81 taps):
+        // with all 144 taps on the 169 pixel threads the fourth wave sat idle for the longest phase of the kernel (28 % of it).  The
+        // two partial sums land in gbuf / gbufb and are added where they are read (dW1 gathers below).
 #if defined(CNN_ABL) && CNN_ABL == 2
-        if (own) for (int ci = 0; ci < C1; ++ci) gbuf[ci * PC + tid] = dzp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1];
+        if (own) for (int ci = 0; ci < C1; ++ci) { gbuf[ci * PC + tid] = dzp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1]; gbufb[ci * PC + tid] = 0.0f; }
         if (false) {
 #else
-        if (own) {
+        {
 #endif
-            float g[C1];
+            auto dp1 = [&](int qy, int qx, int cell_, int co_lo, int co_hi, float* dst) {
+                float g[C1];
 #pragma unroll
-            for (int ci = 0; ci < C1; ++ci) g[ci] = 0.0f;
+                for (int ci = 0; ci < C1; ++ci) g[ci] = 0.0f;
 #pragma unroll 1
-            for (int co = 0; co < C2; ++co)
+                for (int co = co_lo; co < co_hi; ++co)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float v = dzp[co * PP_PLANE + (py + 2 - ky) * PP_RS + px + 2 - kx];
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float v = dzp[co * PP_PLANE + (qy + 2 - ky) * PP_RS + qx + 2 - kx];
 #pragma unroll
-                        for (int q = 0; q < C1; ++q) g[q] = __builtin_fmaf(w2b[((co * 3 + ky) * 3 + kx) * C1 + q], v, g[q]);
-                    }
+                            for (int q = 0; q < C1; ++q) g[q] = __builtin_fmaf(w2b[((co * 3 + ky) * 3 + kx) * C1 + q], v, g[q]);
+                        }
+                float gate[C1];                         // all eight reads before the first write: the compiler cannot tell dst from pp
 #pragma unroll
-            for (int ci = 0; ci < C1; ++ci)
-                gbuf[ci * PC + tid] = (pp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1] > 0.0f) ? g[ci] : 0.0f;
+                for (int ci = 0; ci < C1; ++ci) gate[ci] = pp[ci * PP_PLANE + (qy + 1) * PP_RS + qx + 1];
+#pragma unroll
+                for (int ci = 0; ci < C1; ++ci) dst[ci * PC + cell_] = (gate[ci] > 0.0f) ? g[ci] : 0.0f;
+            };
+            if (wave < 3) {
+                if (own) dp1(py, px, tid, 0, DP1_SPLIT, gbuf);
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 3; ++k) {
+                    const int cell_ = lane + 64 * k;
+                    if (cell_ < PC) { const int qy = cell_ / PW; dp1(qy, cell_ - qy * PW, cell_, DP1_SPLIT, C2, gbufb); }
+                }
+            }
         }
         __syncthreads();
         // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel (no branch on g == 0: a dead
@@ -470,7 +488,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 #pragma unroll 2
         for (int c = grp; c < PC; c += NGRP) {
             const int tab = celloff[c], cid = tab & 255;
-            const float gv = gbuf[co1 * PC + cid];
+            const float gv = gbuf[co1 * PC + cid] + gbufb[co1 * PC + cid];
             const int am = ambuf[cid * C1 + co1];
             const float* base = xp + (c0g * CG) * XP_PLANE_B + (tab >> 8) + (am >> 1) * XP_RS + (am & 1);
 #pragma unroll
@@ -492,7 +510,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 const int y = r + st_dy, x = c + st_dx;
                 if (y >= 0 && y < 2 * PW && x >= 0 && x < 2 * PW) {
                     const int pcell = (y >> 1) * PW + (x >> 1);
-                    if (ambuf[pcell * C1 + st_co] == (((y & 1) << 1) | (x & 1))) gst += gbuf[st_co * PC + pcell];
+                    if (ambuf[pcell * C1 + st_co] == (((y & 1) << 1) | (x & 1))) gst += gbuf[st_co * PC + pcell] + gbufb[st_co * PC + pcell];
                 }
             }
         }
@@ -546,7 +564,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 
 inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE) + 2 * 9 * C1); }
 inline size_t bwd_lds(int) {
-    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + C1 * PC) * 4 + C1 * PC + PC * 4;
+    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + 2 * C1 * PC) * 4 + C1 * PC + PC * 4;
     size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
