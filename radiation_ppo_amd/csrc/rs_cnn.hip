@@ -350,7 +350,6 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate: output channels 0..12 of conv2
     float* gbufb = gbuf + C1 * PC;                  // [8][169]      ... and 13..15 (the helper wave's share)
     uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbufb + C1 * PC);     // [169][8]
-    int* celloff = reinterpret_cast<int*>(ambuf + C1 * PC);           // [169] offset of a cell's 2x2 block inside a padded plane
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id as a scalar
     constexpr int NWAVE = CNN_NT_BWD / 64;
@@ -367,31 +366,29 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     // channels take their weight gradients from 9-element gathers instead (gst below).
     constexpr int CG = DP / 2, NCOMBO = C1 * 2, NGRP = CNN_NT_BWD / NCOMBO, AW = CG * 9 + 1;     // 16 combos x (threads / 16) groups
     float gst = 0.0f;                               // actor: thread (which, co, tap) of the 2 x 8 x 9 stamp gradients, tid < 144
-    const int st_which = tid / (C1 * 9), st_co = (tid - st_which * (C1 * 9)) / 9, st_kk = tid % 9;
-    const int st_dy = 1 - st_kk / 3, st_dx = 1 - st_kk % 3;
+    int st_pack;                                    // which | co << 1 | (2 - ky) << 4 | (2 - kx) << 6: one register across the image loop
+    {
+        const int st_which = tid / (C1 * 9), st_co = (tid - st_which * (C1 * 9)) / 9, st_kk = tid % 9;
+        st_pack = (st_which & 1) | (st_co << 1) | ((2 - st_kk / 3) << 4) | ((2 - st_kk % 3) << 6);
+    }
     float aw1[AW];
 #pragma unroll
     for (int k = 0; k < AW; ++k) aw1[k] = 0.0f;
     const int combo = tid % NCOMBO, grp = tid / NCOMBO;
     const int co1 = combo & 7, c0g = combo >> 3;
-    // Cells are walked column-major, so the 4 cells a wave gathers at once share cx and differ in cy: their window
-    // offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks (bank mod 4 in {0,1}), and the second channel half (2 planes =
-    // 1582 floats = +14 banks: bank mod 4 in {2,3}) takes the other 16 -> the 9-tap gathers are conflict-free (row-major
-    // neighbours collided 2-3 way).
-    for (int e = tid; e < PC; e += CNN_NT_BWD) {
-        const int cy = e % PW, cx = e / PW;
-        celloff[e] = (((2 * cy) * XP_RS + 2 * cx) << 8) | (cy * PW + cx);
-    }
+    // Cells are walked column-major (walk index e -> cell (e % 13, e / 13)), so the 4 cells a wave gathers at once share cx and
+    // differ in cy: their window offsets 56*cy + {0,1,28,29} fall into 16 distinct LDS banks (bank mod 4 in {0,1}), and the second
+    // channel half (2 planes = 1582 floats = +14 banks: bank mod 4 in {2,3}) takes the other 16 -> the 9-tap gathers are
+    // conflict-free (row-major neighbours collided 2-3 way).
     // MFMA operand coordinates of this lane
     const int mrow = lane & 15, mk = lane >> 4;
-    int bci[5], bky[5], bkx[5], bmode[5];           // B column n = 16*tile + mrow -> (ci,ky,kx) / ones / zero
+    int boff[5];                                    // B column n = 16*tile + mrow -> offset of tap (ci,ky,kx) in the padded P1 planes
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
-        const int n = 16 * t + mrow;
-        bmode[t] = (n < 72) ? 0 : ((n == 72) ? 1 : 2);
-        const int nn = (n < 72) ? n : 0;
-        bci[t] = nn / 9; bky[t] = (nn % 9) / 3; bkx[t] = nn % 3;
+        const int n = 16 * t + mrow, nn = (n < 72) ? n : 0;
+        boff[t] = (nn / 9) * PP_PLANE + ((nn % 9) / 3) * PP_RS + nn % 3;
     }
+    const int b4mode = (mrow < 8) ? 0 : ((mrow == 8) ? 1 : 2);        // tile 4 only: columns 64..71 taps, 72 = ones (db2), 73.. = zero
     CnnFetch<CNN_NT_BWD> f;
     v4f fp1a = (v4f){0.f, 0.f, 0.f, 0.f}, fp1b = fp1a;
     float fda2[C2];
@@ -427,17 +424,33 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         __syncthreads();
         // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
 #if !(defined(CNN_ABL) && CNN_ABL == 3)
-        for (int st = wave; st < 43; st += NWAVE) {
-            const int pxl = 4 * st + mk;
-            const bool ok = pxl < PC;
-            const int pq = ok ? pxl : (PC - 1);
-            const int y = pq / PW, x = pq - y * PW;
-            const float av = ok ? dzp[mrow * PP_PLANE + (y + 1) * PP_RS + x + 1] : 0.0f;
+        {
+            // operands of step st + NWAVE are read from LDS while the five MFMAs of step st run (one exposed LDS round trip per wave
+            // and image instead of two per step)
+            auto operands = [&](int st, float& av, float (&bv)[5]) {
+                const int pxl = 4 * st + mk;
+                const bool ok = pxl < PC;
+                const int pq = ok ? pxl : (PC - 1);
+                const int y = pq / PW, x = pq - y * PW;
+                const float a = dzp[mrow * PP_PLANE + (y + 1) * PP_RS + x + 1];
+                av = ok ? a : 0.0f;
+                const float* pyx = pp + y * PP_RS + x;
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                float bv = pp[bci[t] * PP_PLANE + (y + bky[t]) * PP_RS + x + bkx[t]];
-                bv = (bmode[t] == 0) ? bv : ((bmode[t] == 1) ? 1.0f : 0.0f);
-                accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accw[t], 0, 0, 0);
+                for (int t = 0; t < 5; ++t) bv[t] = pyx[boff[t]];
+                bv[4] = (b4mode == 0) ? bv[4] : ((b4mode == 1) ? 1.0f : 0.0f);
+            };
+            float av_n = 0.0f, bv_n[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            operands(wave, av_n, bv_n);                             // wave < NWAVE <= 43
+#pragma unroll 1
+            for (int st = wave; st < 43; st += NWAVE) {
+                const float av = av_n;
+                float bv[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) bv[t] = bv_n[t];
+                if (st + NWAVE < 43) operands(st + NWAVE, av_n, bv_n);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the next step's six DS reads go out first ...
+#pragma unroll
+                for (int t = 0; t < 5; ++t) accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], accw[t], 0, 0, 0);
             }
         }
 #endif
@@ -485,29 +498,50 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel (no branch on g == 0: a dead
         // cell adds zeros; the phase is instruction-issue bound, so the index work is shared by CG channels)
 #if !(defined(CNN_ABL) && CNN_ABL == 1)
-#pragma unroll 2
-        for (int c = grp; c < PC; c += NGRP) {
-            const int tab = celloff[c], cid = tab & 255;
-            const float gv = gbuf[co1 * PC + cid] + gbufb[co1 * PC + cid];
-            const int am = ambuf[cid * C1 + co1];
-            const float* base = xp + (c0g * CG) * XP_PLANE_B + (tab >> 8) + (am >> 1) * XP_RS + (am & 1);
+        {
+            // software-pipelined by hand: the next cell's gradient / arg-max reads are in flight while this cell's 18 window values are
+            // read in ONE round trip and accumulated.  (The compiler's own schedule, tuned for register pressure, waited for every
+            // ds_read before the FMA that uses it: ~12 exposed LDS latencies per cell, a fifth of the kernel.)
+            int cy = grp % PW, cx = grp / PW;                           // cell e = grp + 16 k of the column-major walk: (e % 13, e / 13)
+            auto cell_inputs = [&](int cy_, int cx_, float& gv_, int& off_) {
+                const int cid = cy_ * PW + cx_;
+                const float ga = gbuf[co1 * PC + cid], gb = gbufb[co1 * PC + cid];
+                const int am = ambuf[cid * C1 + co1];
+                gv_ = ga + gb;
+                off_ = (2 * cy_ + (am >> 1)) * XP_RS + 2 * cx_ + (am & 1);
+            };
+            float gv_n; int off_n;
+            cell_inputs(cy, cx, gv_n, off_n);
+#pragma unroll 1
+            for (int c = grp; c < PC; c += NGRP) {
+                const float gv = gv_n;
+                const float* base = xp + (c0g * CG) * XP_PLANE_B + off_n;
+                float wv[CG * 9];
 #pragma unroll
-            for (int j = 0; j < CG; ++j)
+                for (int j = 0; j < CG; ++j)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        aw1[j * 9 + ky * 3 + kx] = __builtin_fmaf(gv, base[j * XP_PLANE_B + ky * XP_RS + kx], aw1[j * 9 + ky * 3 + kx]);
-            aw1[AW - 1] += gv;
+                        for (int kx = 0; kx < 3; ++kx) wv[j * 9 + ky * 3 + kx] = base[j * XP_PLANE_B + ky * XP_RS + kx];
+                cy += NGRP - PW; cx += 1;                               // e += 16 = 13 + 3
+                if (cy >= PW) { cy -= PW; cx += 1; }
+                if (c + NGRP < PC) cell_inputs(cy, cx, gv_n, off_n);
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);     // all DS reads of the round first ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);     // ... then the VALU work
+#pragma unroll
+                for (int k = 0; k < CG * 9; ++k) aw1[k] = __builtin_fmaf(gv, wv[k], aw1[k]);
+                aw1[AW - 1] += gv;
+            }
         }
 #endif
         if (CIN == 6 && tid < 2 * C1 * 9) {
             // one-hot input at (r, c): tap (ky, kx) of conv1 meets it at output pixel (r - ky + 1, c - kx + 1); that pixel carries
             // gradient iff it is its pool window's arg-max for channel co
-            const int cell = st_which ? loc : pc;
+            const int st_co = (st_pack >> 1) & 7;
+            const int cell = (st_pack & 1) ? loc : pc;
             if (cell >= 0) {
                 const int r = cell / MAPW, c = cell - r * MAPW;
-                const int y = r + st_dy, x = c + st_dx;
+                const int y = r + ((st_pack >> 4) & 3) - 1, x = c + ((st_pack >> 6) & 3) - 1;
                 if (y >= 0 && y < 2 * PW && x >= 0 && x < 2 * PW) {
                     const int pcell = (y >> 1) * PW + (x >> 1);
                     if (ambuf[pcell * C1 + st_co] == (((y & 1) << 1) | (x & 1))) gst += gbuf[st_co * PC + pcell] + gbufb[st_co * PC + pcell];
@@ -564,7 +598,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 
 inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE) + 2 * 9 * C1); }
 inline size_t bwd_lds(int) {
-    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + 2 * C1 * PC) * 4 + C1 * PC + PC * 4;
+    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + 2 * C1 * PC) * 4 + C1 * PC;
     size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
