@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+#include "rs_sstream.hpp"
 
 namespace {
 
@@ -26,34 +27,9 @@ constexpr int G3 = 3 * GH;                   // 72
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 
-// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16): one k row per
-// s_load_dwordx16, rows requested two ahead, every row closed by a scheduling barrier with the accumulators pinned (otherwise the
-// loads are hoisted to the top of the step, spilled to VGPR lanes and read back one v_readlane per FMA operand: 4 658 of them in
-// the forward step, half its time)
+// out[OUTP] += W^T c through the scalar-unit weight stream (csrc/rs_sstream.hpp: wait -> request -> FMA blocks of two rows)
 template <int K, int OUTP, typename F>
-__device__ __forceinline__ void gru_matvec(cmem_t W, F cval, float (&out)[OUTP]) {
-#pragma unroll
-    for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wq[3][16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wq[0][o] = W[16 * ch + o]; wq[1][o] = W[OUTP + 16 * ch + o]; }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k + 2 < K) {
-#pragma unroll
-                for (int o = 0; o < 16; ++o) wq[(k + 2) % 3][o] = W[(k + 2) * OUTP + 16 * ch + o];
-            }
-            const float c = cval(k);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % 3][o], c, acc[o]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) out[16 * ch + o] = acc[o];
-    }
-}
+__device__ __forceinline__ void gru_matvec(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
 
 // sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each), branch free
 __device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }

@@ -54,33 +54,38 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit.  Two k rows (2 x s_load_dwordx16 per
-// 16-output chunk) form a block; the next block's rows are requested before the current block's 32 FMAs and a scheduling
-// barrier closes every block, so at most two blocks (64 SGPRs) are live: without it the scheduler hoists dozens of the
-// (independent) loads, runs out of SGPRs and spills them through v_writelane / v_readlane (measured: 1 389 loads and 2 756
-// v_readlane in 21 k instructions for this kernel, 419 us per step at config 4).
+// 16-output chunk) form a block, double buffered (64 SGPRs live); a scheduling barrier closes every block: without it the scheduler
+// hoists dozens of the (independent) loads, runs out of SGPRs and spills them through v_writelane / v_readlane (measured: 1 389 loads
+// and 2 756 v_readlane in 21 k instructions for this kernel, 419 us per step at config 4).  Inside a block the order is
+//     wait for this block's rows  ->  request the next block  ->  32 FMAs:
+// scalar loads return out of order, the only wait is lgkmcnt(0) and it drains everything in flight, so a request issued BEFORE the wait
+// (hipcc's own order) is waited for at once.  The empty asm "reads" the current rows and so pins the wait in front of the requests.
+#define PF_ARRIVED(w) asm volatile("" :: "s"((w)[0]), "s"((w)[16]))
 template <int WOFF, int BOFF, typename F>
 __device__ __forceinline__ void pf_matvec48(cmem_t W, F cval, float (&out)[48]) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float acc[16], wa[32], wb[32];
+        float acc[16], wq[2][32];
 #pragma unroll
         for (int o = 0; o < 16; ++o) acc[o] = W[BOFF + 16 * ch + o];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) wa[i] = W[WOFF + (i >> 4) * 48 + 16 * ch + (i & 15)];
+        for (int i = 0; i < 32; ++i) wq[0][i] = W[WOFF + (i >> 4) * 48 + 16 * ch + (i & 15)];
 #pragma unroll
         for (int b = 0; b < PF_KP / 2; ++b) {
+            float (&cur)[32] = wq[b & 1];
+            PF_ARRIVED(cur);
+            __builtin_amdgcn_sched_barrier(0);
             if (b + 1 < PF_KP / 2) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i) wb[i] = W[WOFF + (2 * (b + 1) + (i >> 4)) * 48 + 16 * ch + (i & 15)];
+                for (int i = 0; i < 32; ++i) wq[(b + 1) & 1][i] = W[WOFF + (2 * (b + 1) + (i >> 4)) * 48 + 16 * ch + (i & 15)];
             }
+            __builtin_amdgcn_sched_barrier(0);
             const float c0 = cval(2 * b), c1 = cval(2 * b + 1);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[o], c0, acc[o]);
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[o], c0, acc[o]);
 #pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wa[16 + o], c1, acc[o]);
+            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[16 + o], c1, acc[o]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) wa[i] = wb[i];
         }
 #pragma unroll
         for (int o = 0; o < 16; ++o) {

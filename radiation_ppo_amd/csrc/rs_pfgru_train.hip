@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+#include "rs_sstream.hpp"
 
 // Diagnostic build only (-DRS_K13_STAMPS, scripts/k13_stamps.py): s_memtime stamps at the phase boundaries of a step, summed per wave
 // and added to a device table at the end of the episode.  Read the SHARES (the stamps serialise what the product kernel overlaps).
@@ -75,89 +76,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit (OUTP a multiple of 16, K even).
-// Weight rows travel in blocks of two (2 x s_load_dwordx16 = 32 SGPRs, double buffered).  Scalar loads return out of order, so the only
-// wait there is, lgkmcnt(0), drains EVERYTHING in flight: the order inside a block therefore has to be
-//     wait for this block's rows  ->  request the next block  ->  32 FMAs,
-// which gives the next rows the whole FMA run (80 cycles) to arrive; one x16 load costs a wave ~44 cycles
-// (scripts/micro/sload_latency.hip).  Left to itself hipcc requests the next rows first and waits right behind them -- at one wave per
-// SIMD that exposed a full scalar round trip for every second or third row.  The empty asm that "reads" the current rows pins the wait
-// in front of the requests; scheduling barriers keep the three parts in that order.
-// See K11 / K12 for the other code-generation remedies (results pinned); here the accumulators are pinned at EVERY row as well: pinned
-// only at the end, a whole chunk's FMA chains were still sunk below the barriers in the backward loop.
-#define PF_ARRIVED(w) asm volatile("" :: "s"((w)[0]), "s"((w)[16]))
+// The scalar-unit weight streams (wait -> request -> FMA blocks): csrc/rs_sstream.hpp
 template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
-    static_assert(K % 2 == 0 && OUTP % 16 == 0, "two rows per block");
-#pragma unroll
-    for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wq[2][32];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = out[16 * ch + o];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) wq[0][i] = W[(i >> 4) * OUTP + 16 * ch + (i & 15)];
-#pragma unroll
-        for (int b = 0; b < K / 2; ++b) {
-            float (&cur)[32] = wq[b & 1];
-            PF_ARRIVED(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (b + 1 < K / 2) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) wq[(b + 1) & 1][i] = W[(2 * (b + 1) + (i >> 4)) * OUTP + 16 * ch + (i & 15)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float c0 = cval(2 * b), c1 = cval(2 * b + 1);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[o], c0, acc[o]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[16 + o], c1, acc[o]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            asm volatile("" : "+v"(acc[o]));
-            out[16 * ch + o] = acc[o];
-        }
-    }
-}
-
-// out[k] += sum_o W[k][o] c(o) on the SAME k-major [K][OUTP] block (the transposed product of the backward pass: a dot product
-// along each row).  Two 16-weight pieces per block, the same wait -> request -> FMA order, two partial sums per row.
+__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
 template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
-    constexpr int CH = OUTP / 16, NB = K * CH;
-    static_assert(NB % 2 == 0, "two pieces per block");
-    float wq[2][32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) wq[0][i] = W[i];
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int b2 = 0; b2 < NB / 2; ++b2) {
-        float (&cur)[32] = wq[b2 & 1];
-        PF_ARRIVED(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        if (b2 + 1 < NB / 2) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) wq[(b2 + 1) & 1][i] = W[(b2 + 1) * 32 + i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int b = 2 * b2 + hb, k = b / CH, ch = b % CH;
-            if (ch == 0) { a0 = 0.0f; a1 = 0.0f; }
-#pragma unroll
-            for (int o = 0; o < 16; o += 2) {
-                a0 = fmaf(cur[16 * hb + o], cval(16 * ch + o), a0);
-                a1 = fmaf(cur[16 * hb + o + 1], cval(16 * ch + o + 1), a1);
-            }
-            asm volatile("" : "+v"(a0), "+v"(a1));
-            if (ch == CH - 1) out[k] += a0 + a1;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) { rs_ss_mvt<K, OUTP>(W, cval, out); }
 
 // value of lane L (a constant) in every lane: v_readlane_b32 (one instruction into an SGPR) instead of __shfl's LDS permute
 template <int L>

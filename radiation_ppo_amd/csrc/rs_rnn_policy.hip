@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+#include "rs_sstream.hpp"
 
 namespace {
 
@@ -35,32 +36,9 @@ static_assert(P_STRIDE == RS_RNN_POLICY_WEIGHT_FLOATS, "include/radsearch.h: RS_
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 
-// out[OUTP] += W^T c for a k-major [K][OUTP] block read through the scalar unit: rows requested two ahead, every row closed by a
-// scheduling barrier with the accumulators pinned (see K12 / K13)
+// out[OUTP] += W^T c through the scalar-unit weight stream (csrc/rs_sstream.hpp: wait -> request -> FMA blocks of two rows)
 template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) {
-#pragma unroll
-    for (int ch = 0; ch < OUTP / 16; ++ch) {
-        float acc[16], wq[3][16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) { acc[o] = out[16 * ch + o]; wq[0][o] = W[16 * ch + o]; wq[1][o] = W[OUTP + 16 * ch + o]; }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k + 2 < K) {
-#pragma unroll
-                for (int o = 0; o < 16; ++o) wq[(k + 2) % 3][o] = W[(k + 2) * OUTP + 16 * ch + o];
-            }
-            const float c = cval(k);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(wq[k % 3][o], c, acc[o]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(acc[o]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) out[16 * ch + o] = acc[o];
-    }
-}
+__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
 
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x)); }
@@ -166,32 +144,9 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     }
 }
 
-// out[k] += sum_o W[k][o] c(o) on a k-major [K][OUTP] block (the transposed product: a dot product along each row), as K13's mvt
+// out[k] += sum_o W[k][o] c(o) on a k-major [K][OUTP] block (the transposed product: a dot product along each row)
 template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) {
-    constexpr int CH = OUTP / 16, NB = K * CH;
-    float wq[3][16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) { wq[0][o] = W[o]; wq[1][o] = W[16 + o]; }
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        if (b + 2 < NB) {
-#pragma unroll
-            for (int o = 0; o < 16; ++o) wq[(b + 2) % 3][o] = W[(b + 2) * 16 + o];
-        }
-        const int k = b / CH, ch = b % CH;
-        if (ch == 0) { a0 = 0.0f; a1 = 0.0f; }
-#pragma unroll
-        for (int o = 0; o < 16; o += 2) {
-            a0 = fmaf(wq[b % 3][o], cval(16 * ch + o), a0);
-            a1 = fmaf(wq[b % 3][o + 1], cval(16 * ch + o + 1), a1);
-        }
-        asm volatile("" : "+v"(a0), "+v"(a1));
-        if (ch == CH - 1) out[k] += a0 + a1;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) { rs_ss_mvt<K, OUTP>(W, cval, out); }
 
 // K15: heads, per-sample PPO-clip / value loss and their back-propagation for every (step, episode) sample of an episode chunk:
 // update_rada2c's loss (algos/multiagent/ppo.py:1191-1234) behind the GRU.  One sample per lane.  Writes dL/dh (the input of K12's
