@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+#include "rs_wave.hpp"
 
 namespace {
 
@@ -42,16 +43,8 @@ __device__ __forceinline__ uint64_t pf_hash(uint64_t key) {
     return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return rs_wave_max(v); }     // csrc/rs_wave.hpp: DPP rows + v_readlane, no LDS
+__device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
 
 // out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit.  Two k rows (2 x s_load_dwordx16 per
 // 16-output chunk) form a block, double buffered (64 SGPRs live); a scheduling barrier closes every block: without it the scheduler
@@ -200,12 +193,8 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     const float al = a_.alpha, floor_ = a_.floor_;
     {
         double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {                         // inclusive scan over the lanes (float64)
-            const double t = __shfl_up(c, s);
-            if (lane >= s) c += t;
-        }
-        const double tot = __shfl(c, PF_P - 1);
+        c = rs_wave_scan(c);                                       // inclusive scan over the lanes (float64) on the DPP path
+        const double tot = rs_lane_d<PF_P - 1>(c);
         if (act) cdf[lane] = c / tot;
 #pragma unroll
         for (int u = 0; u < PF_H; ++u) if (act) tile[lane * PF_ROW + u] = h1[u];

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
+#include "rs_wave.hpp"
 #include "rs_sstream.hpp"
 
 // Diagnostic build only (-DRS_K13_STAMPS, scripts/k13_stamps.py): s_memtime stamps at the phase boundaries of a step, summed per wave
@@ -65,16 +66,8 @@ typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return rs_wave_max(v); }     // csrc/rs_wave.hpp: DPP rows + v_readlane, no LDS
+__device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
 
 // The scalar-unit weight streams (wait -> request -> FMA blocks): csrc/rs_sstream.hpp
 template <int K, int OUTP, typename F>
@@ -177,30 +170,26 @@ __device__ __forceinline__ void outer_store(const f4 (&acc)[TI][TJ], float* out,
             }
 }
 
-__global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
-    __shared__ __align__(16) float smem[LDS_FLOATS];
+// The forward walk of a training pass as its own launch (round 3).  Inside the 512-register backward kernel it ran at one wave per SIMD,
+// where a lone wave issues a VALU instruction only every ~5 cycles (scripts/micro/sload_latency.hip: 32 v_fmac = 180 cycles; two or
+// more waves share the SIMD at 2.5): the walk needs no gradient accumulators, fits 2 waves per SIMD without spilling (3 waves: 33 registers spilled) and stores everything the backward
+// walk reads (particle sets, log-weights, resampling indices, gates) exactly as the fused kernel did.
+constexpr int FWD_LDS_FLOATS = TILE_F + 2 * P + 64;
+__global__ void __launch_bounds__(64, 2) rs_pfgru_train_fwd_kernel(TrArgs a_) {
+    __shared__ __align__(16) float smem[FWD_LDS_FLOATS];
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
     float* tile = smem;                                              // [44][ROW]
     double* cdf = reinterpret_cast<double*>(smem + TILE_F);          // [P]
     float* vec = smem + TILE_F + 2 * P;                              // [64]
-    float* DT = vec + 64;                                            // [48][SP]
-    float* IT = DT + DT_F;                                           // [32][SP]
-    float* pre = IT + IT_F;                                          // [P][4 H] gates of one step, flat as in HBM
-    for (int i = lane; i < DT_F + IT_F; i += 64) DT[i] = 0.0f;       // rows 28..31 of IT stay zero for the whole kernel
-
     const bool act = lane < P;
     const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
     K13_DECL
-    // the weight pointer is laundered once per time step and again before every transposed product (wptr): the weights are loop
-    // invariant and the forward and transposed products read the same rows -- LICM / GVN would otherwise hoist or keep thousands of
-    // scalar loads and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
     auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
     const int E = a_.E;
     const int len = (int)a_.lens[e];
     const float al = a_.alpha, floor_ = a_.floor_;
     const size_t PH = (size_t)P * H;
-
     auto load24 = [&](const float* src, float (&dst)[H]) {
 #pragma unroll
         for (int u = 0; u < H; u += 4) {
@@ -213,8 +202,6 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
 #pragma unroll
         for (int k = 0; k < IN; ++k) x[k] = o[k];
     };
-
-    // ------------------------------------------------------------------------------------------ forward through the episode
     {
         float h0[H];
         load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
@@ -244,12 +231,8 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
             const float p1 = (lg - mx) - logf(se);
             double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {                       // inclusive scan over the lanes (float64), as K11
-                const double tt = __shfl_up(c, s);
-                if (lane >= s) c += tt;
-            }
-            const double tot = __shfl(c, P - 1);
+            c = rs_wave_scan(c);                                       // inclusive scan over the lanes (float64) on the DPP path
+            const double tot = rs_lane_d<P - 1>(c);
             if (act) cdf[lane] = c / tot;
 #pragma unroll
             for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = h1[u];
@@ -281,6 +264,45 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             K13_STAMP(1)                                             // forward: softmax, resampling, stores
         }
     }
+
+    K13_FLUSH
+}
+
+__global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
+    __shared__ __align__(16) float smem[LDS_FLOATS];
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    float* tile = smem;                                              // [44][ROW]
+    float* vec = smem + TILE_F + 2 * P;                              // [64]
+    float* DT = vec + 64;                                            // [48][SP]
+    float* IT = DT + DT_F;                                           // [32][SP]
+    float* pre = IT + IT_F;                                          // [P][4 H] gates of one step, flat as in HBM
+    for (int i = lane; i < DT_F + IT_F; i += 64) DT[i] = 0.0f;       // rows 28..31 of IT stay zero for the whole kernel
+
+    const bool act = lane < P;
+    const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
+    K13_DECL
+    // the weight pointer is laundered once per time step and again before every transposed product (wptr): the weights are loop
+    // invariant and the forward and transposed products read the same rows -- LICM / GVN would otherwise hoist or keep thousands of
+    // scalar loads and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
+    auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
+    const int E = a_.E;
+    const int len = (int)a_.lens[e];
+    const float al = a_.alpha, floor_ = a_.floor_;
+    const size_t PH = (size_t)P * H;
+
+    auto load24 = [&](const float* src, float (&dst)[H]) {
+#pragma unroll
+        for (int u = 0; u < H; u += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + u);
+            dst[u] = v.x; dst[u + 1] = v.y; dst[u + 2] = v.z; dst[u + 3] = v.w;
+        }
+    };
+    auto load_x = [&](int t, float (&x)[IN]) {
+        const cmem_t o = as_cmem(a_.obs + ((size_t)t * E + e) * RS_OBS_DIM);
+#pragma unroll
+        for (int k = 0; k < IN; ++k) x[k] = o[k];
+    };
 
     // ------------------------------------------------------------------------------------------ backward through the episode
     f4 accZR[3][2], accN[3][2], accH0[2][2];
@@ -588,6 +610,7 @@ int rs_pfgru_train(const float* weights, const float* obs, const float* target, 
         return RS_ERR_INVALID_ARG;
     TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
              (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
+    hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

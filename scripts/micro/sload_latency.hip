@@ -61,6 +61,29 @@ __global__ void __launch_bounds__(256) stream(const uint32_t* tab, int iters, un
     if (acc == 12345u) sink[0] = acc;
 }
 
+// do scalar loads overlap with VALU work of the same wave?  [2 x16 loads][NF FMAs][wait] against the two parts alone
+template <int NF, bool LOADS>
+__global__ void __launch_bounds__(64) overlap(const uint32_t* tab, int iters, unsigned long long* out, float* sink) {
+    const uint64_t base = (uint64_t)(uintptr_t)tab;
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = threadIdx.x + j;
+    uint32_t acc = 0;
+    unsigned long long t0 = now();
+    for (int i = 0; i < iters; ++i) {
+        u16v a, b;
+        const uint64_t p = base + (uint64_t)((i & 15) * 1024);
+        if (LOADS) asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(a), "=s"(b) : "s"(p) : "memory");
+#pragma unroll
+        for (int k = 0; k < NF; ++k) asm volatile("v_fmac_f32 %0, 0x3f800347, %0" : "+v"(f[k & 15]));
+        if (LOADS) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); acc += a[0] + b[1]; }
+    }
+    unsigned long long t1 = now();
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    float s = 0; for (int j = 0; j < 16; ++j) s += f[j];
+    if (s == 1.2345f || acc == 12345u) sink[0] = s;
+}
+
 int main() {
     const int n = 4096;
     uint32_t* tab; unsigned long long* out;
@@ -97,6 +120,18 @@ int main() {
             printf("x16 stream, %2d waves per CU: wave 0 %.1f ticks per x16 load; kernel %.3f ms -> %.2f x16 loads per us per CU\n", wpc,
                    (double)w0 / (iters * 4.0), ms, (double)wpc * iters * 4 / (ms * 1e3));
         }
+    }
+    {
+        unsigned long long* o3; float* fs; hipMalloc(&o3, 64); hipMalloc(&fs, 4);
+        unsigned long long r[3]; const int it = 4000;
+        overlap<0, true><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[0], o3, 8, hipMemcpyDeviceToHost);
+        overlap<32, false><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[1], o3, 8, hipMemcpyDeviceToHost);
+        overlap<32, true><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[2], o3, 8, hipMemcpyDeviceToHost);
+        printf("one wave: 2 x16 loads + wait %.1f ticks; 32 v_fmac %.1f ticks; loads, 32 v_fmac, wait %.1f ticks per round\n",
+               (double)r[0] / it, (double)r[1] / it, (double)r[2] / it);
+        overlap<64, false><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[1], o3, 8, hipMemcpyDeviceToHost);
+        overlap<64, true><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[2], o3, 8, hipMemcpyDeviceToHost);
+        printf("one wave: 64 v_fmac %.1f ticks; loads, 64 v_fmac, wait %.1f ticks per round\n", (double)r[1] / it, (double)r[2] / it);
     }
     // s_memtime runs at a fixed 100 MHz on this part: print the ratio to the shader clock measured with a VALU loop elsewhere
     return 0;
