@@ -469,7 +469,7 @@ class RNNAgentPPO:
                  actor_critic_args: Optional[Dict[str, Any]] = None, train_pi_iters: int = 40, train_pfgru_iters: int = 15,
                  actor_learning_rate: float = 3e-4, pfgru_learning_rate: float = 5e-3, gamma: float = 0.99, alpha: float = 0.1,
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, bp_args: Optional[Any] = None,
-                 env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 8192,
+                 env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 32768,
                  GlobalCriticOptimizer=None, **unused: Any):
         if actor_critic_architecture != "rnn":
             raise ValueError("Unsupported Neural Network type requested")
