@@ -471,6 +471,10 @@ class RNNAgentPPO:
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, bp_args: Optional[Any] = None,
                  env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 32768,
                  GlobalCriticOptimizer=None, **unused: Any):
+        # episode_chunk: episodes per pass of the update kernels.  One chunk for a whole 4096-env epoch (~16.5 k episodes): the recurrent
+        # kernels (K12: one episode per lane) and the K11 passes are latency bound per launch, so three 8192-episode chunks cost three times
+        # one 16 k chunk (RAD-A2C bench: 895 -> 972 k env steps/s).  K13's scratch grows with it: 1.8 MB per full-length episode (gates,
+        # particle sets, noise) = ~30 GB at 16.5 k episodes, 60 GB at the cap -- sized for the 288 GB of an MI355X.
         if actor_critic_architecture != "rnn":
             raise ValueError("Unsupported Neural Network type requested")
         if GlobalCriticOptimizer is not None:
