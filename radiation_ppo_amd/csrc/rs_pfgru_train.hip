@@ -1,5 +1,5 @@
-// rs_pfgru_train.hip -- K13: loss and parameter gradients of the PFGRU location predictor over whole episodes, one launch per
-// pass of update_model.
+// rs_pfgru_train.hip -- K13: loss and parameter gradients of the PFGRU location predictor over whole episodes, one call (a forward-
+// walk launch and a backward-walk launch) per pass of update_model.
 //
 // Replaces the body of AgentPPO.update_model's iteration (algos/multiagent/ppo.py:1062-1128: the PFGRU unrolled through every
 // episode, the regression + ELBO loss on the mean prediction and on every particle's prediction, loss.backward()) that
@@ -8,14 +8,14 @@
 // resampling :1466-1515, reparameterize :1517-1530, as in K11 (rs_pfgru.hip).
 //
 // Mapping: one wave per episode, one particle per lane (40 of 64; lane 40 carries the weighted-mean "particle" through hid_obs).
-// The wave first runs the episode forward, storing every step's resampled particle set (3.9 KB per step) and the step's gates
+// The forward kernel's wave runs the episode forward, storing every step's resampled particle set (3.9 KB per step) and the step's gates
 // z, r, n and eps * softplus'(var) (15 KB per step; round 3 -- round 2 recomputed them from the stored input state, 21 % of the kernel),
-// then walks it backwards: each step's gates are reloaded, the loss terms of the step are formed
+// then the backward kernel's wave walks it backwards: each step's gates are reloaded, the loss terms of the step are formed
 // and differentiated in registers, and the gradient flows to the previous step's particles through the resampling gather (an
 // LDS scatter-add) and the gates.  The small matrix products use wave-uniform weights through the scalar unit (as K11 / K12);
 // the weight gradients are sums over particles of outer products: the per-particle factors are staged transposed in LDS and
 // accumulated on the matrix cores (v_mfma_f32_16x16x4_f32, contraction over the particles) in registers for the whole episode,
-// the two thin ones (fc_obs, hid_obs[2]) in per-lane accumulators reduced once at the end.  Output: one gradient slab and one
+// the two thin ones (fc_obs, hid_obs[2]) as rows of one more tile each.  Output: one gradient slab and one
 // weighted loss per episode; the caller sums them (fixed order).
 //
 // Resampling indices are constants of the backward pass, as in autograd (torch.searchsorted / multinomial have no gradient).

@@ -675,7 +675,7 @@ class RNNAgentPPO:
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it, H=self.agent.rec, hid=self.agent.hid)
                 if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
-                    # K13: the episode loop, the loss and its back-propagation through time in one launch
+                    # K13: the episode loop, the loss and its back-propagation through time in one call (two launches)
                     loss, g, _ = self.model_pass_hip(B, sl, d)
                     by_name = unpack_train_grads(cell, g)
                     for name, p in cell.named_parameters():
