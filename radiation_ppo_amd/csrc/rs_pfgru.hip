@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/radsearch.h"
-#include "rs_wave.hpp"
+#include "rs_sstream.hpp"
 
 namespace {
 
@@ -43,51 +43,16 @@ __device__ __forceinline__ uint64_t pf_hash(uint64_t key) {
     return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ float wave_max(float v) { return rs_wave_max(v); }     // csrc/rs_wave.hpp: DPP rows + v_readlane, no LDS
-__device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
 
-// out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit.  Two k rows (2 x s_load_dwordx16 per
-// 16-output chunk) form a block, double buffered (64 SGPRs live); a scheduling barrier closes every block: without it the scheduler
-// hoists dozens of the (independent) loads, runs out of SGPRs and spills them through v_writelane / v_readlane (measured: 1 389 loads
-// and 2 756 v_readlane in 21 k instructions for this kernel, 419 us per step at config 4).  Inside a block the order is
-//     wait for this block's rows  ->  request the next block  ->  32 FMAs:
-// scalar loads return out of order, the only wait is lgkmcnt(0) and it drains everything in flight, so a request issued BEFORE the wait
-// (hipcc's own order) is waited for at once.  The empty asm "reads" the current rows and so pins the wait in front of the requests.
-#define PF_ARRIVED(w) asm volatile("" :: "s"((w)[0]), "s"((w)[16]))
+// out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit: the shared weight stream of K12 - K15
+// (csrc/rs_sstream.hpp: two-row blocks in wait -> request -> FMA order, accumulators pinned at every block -- pinned only at the end of
+// a chunk, the lane-packed kernel below had single output chains sunk to their use, every row spilled to VGPR lanes and restored
+// sixteen v_readlane per FMA: 10 494 of them, 530 us per step).
 template <int WOFF, int BOFF, typename F>
 __device__ __forceinline__ void pf_matvec48(cmem_t W, F cval, float (&out)[48]) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        float acc[16], wq[2][32];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[BOFF + 16 * ch + o];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) wq[0][i] = W[WOFF + (i >> 4) * 48 + 16 * ch + (i & 15)];
-#pragma unroll
-        for (int b = 0; b < PF_KP / 2; ++b) {
-            float (&cur)[32] = wq[b & 1];
-            PF_ARRIVED(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (b + 1 < PF_KP / 2) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) wq[(b + 1) & 1][i] = W[WOFF + (2 * (b + 1) + (i >> 4)) * 48 + 16 * ch + (i & 15)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float c0 = cval(2 * b), c1 = cval(2 * b + 1);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[o], c0, acc[o]);
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[o] = fmaf(cur[16 + o], c1, acc[o]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            // materialise the result here: otherwise the compiler sinks each output's FMA chain to its use (to save VGPRs) and
-            // re-reads a whole 16-dword row per FMA (seen in the ISA: one s_load_dwordx16 + s_waitcnt per v_fmac)
-            asm volatile("" : "+v"(acc[o]));
-            out[16 * ch + o] = acc[o];
-        }
-    }
+    for (int o = 0; o < 48; ++o) out[o] = W[BOFF + o];
+    rs_ss_mv<PF_KP, 48>(W + WOFF, cval, out);
 }
 
 struct PfArgs {
@@ -107,39 +72,71 @@ struct PfArgs {
 };
 
 constexpr int PF_ROW = PF_H + 1;                                   // odd row stride: conflict-free row writes and column reads
-constexpr int PF_LDS_WAVE = PF_P * PF_ROW * 4 + PF_P * 8 + 64 * 4; // h tile, cdf (f64), p1 / mean
+// Lane packing (round 3): six (owner, env) sets of 40 particles share a 256-thread workgroup -- 240 of 256 lanes carry a particle
+// where one set per wave used 40 of 64.  A set's lanes straddle waves, so what couples its particles goes through LDS and workgroup
+// barriers instead of wave operations: every lane reads the set's 40 values back (broadcast ds_read_b128) and reduces them itself in
+// index order -- deterministic and independent of which sets share the workgroup.  Nine barriers per step cost 1.5 % (measured by
+// putting them into the one-set-per-wave kernel); the lanes gained are 1.5x.  Four waves per workgroup = one per SIMD, three workgroups per
+// CU at 168 VGPRs (nine sets on 384 threads left the second workgroup without room on two of the SIMDs: 188 us per step).
+constexpr int PK_SETS = 6, PK_NT = 256;
+// LDS of one set (floats): tile [40][25] | cdf 40 x f64 | va [40] | vb [40] | vc [40] | vm [24] (+ pad); the stride is 12 (mod 32) banks so
+// that the up to three sets a wave touches read different banks
+constexpr int PK_TILE = 0, PK_CDF = PF_P * PF_ROW, PK_VA = PK_CDF + 2 * PF_P, PK_VB = PK_VA + PF_P, PK_VC = PK_VB + PF_P,
+              PK_VM = PK_VC + PF_P, PK_STRIDE = 1228;
+static_assert(PK_VM + PF_H <= PK_STRIDE && PK_STRIDE % 4 == 0 && PK_STRIDE % 32 == 12 && PK_CDF % 2 == 0, "LDS layout of a particle set");
+
+__device__ __forceinline__ float pk_max40(const float* v) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PF_P / 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(v)[i];
+        m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+    }
+    return m;
+}
+__device__ __forceinline__ float pk_sum40(const float* v) {          // index order
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PF_P / 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(v)[i];
+        s = (((s + t.x) + t.y) + t.z) + t.w;
+    }
+    return s;
+}
 
 template <bool REC>
-__global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long wv = (long long)blockIdx.x * 4 + wid;
-    if (wv >= (long long)a_.A * a_.N) return;                       // whole waves only: no barrier below
-    const int own = __builtin_amdgcn_readfirstlane((int)(wv / a_.N));
-    const int n = __builtin_amdgcn_readfirstlane((int)(wv - (long long)own * a_.N));
+__global__ void __launch_bounds__(PK_NT, 3) rs_pfgru_kernel(PfArgs a_, int groups) {
+    __shared__ __align__(16) float smem[PK_SETS * PK_STRIDE];
+    const int tid = threadIdx.x;
+    const int own = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)groups));       // one owner per workgroup: wave-uniform weights
+    const int grp = blockIdx.x - own * groups;
+    const int set = tid / PF_P, q = tid - set * PF_P;                // set == PK_SETS: the 16 lanes that carry nothing
+    const int n_raw = grp * PK_SETS + set;
+    const bool in_range = set < PK_SETS && n_raw < a_.N;
+    const int n = in_range ? n_raw : a_.N - 1;                      // lanes without a set shadow the last env (nothing is stored)
     // a masked round (the collectors' bootstrap predictions, train.py:462-480) only counts for the masked envs: the others' rows are
-    // discarded by the caller, so their waves leave at once (a bootstrap round costs the few envs that time out, not all of them)
-    if (a_.mask != nullptr && a_.mask[n] == 0) return;
-    unsigned char* base = smem + (size_t)wid * PF_LDS_WAVE;
-    float* tile = reinterpret_cast<float*>(base);                   // [P][PF_ROW]
-    double* cdf = reinterpret_cast<double*>(base + PF_P * PF_ROW * 4);
-    float* vec = reinterpret_cast<float*>(base + PF_P * PF_ROW * 4 + PF_P * 8);   // [64]
+    // discarded by the caller; a workgroup without a masked env leaves at once
+    const bool live = in_range && (a_.mask == nullptr || a_.mask[n] != 0);
+    if (__syncthreads_or(live ? 1 : 0) == 0) return;
+    float* S = smem + (set < PK_SETS ? set : PK_SETS - 1) * PK_STRIDE;      // (the spare lanes read the last set's area and write nothing)
+    float* tile = S + PK_TILE;
+    double* cdf = reinterpret_cast<double*>(S + PK_CDF);
+    float *va = S + PK_VA, *vb = S + PK_VB, *vc = S + PK_VC, *vm = S + PK_VM;
+    const bool act = set < PK_SETS;                                 // LDS writes allowed (the set's own area)
 
-    const bool act = lane < PF_P;
-    const int pl = act ? lane : PF_P - 1;                           // idle lanes shadow the last particle (values discarded)
     cmem_t W = as_cmem(a_.w + (size_t)own * PF_STRIDE);
     const size_t slot = (size_t)own * a_.N + n;
-    const float* hp = a_.h + (slot * PF_P + pl) * PF_H;
+    const float* hp = a_.h + (slot * PF_P + q) * PF_H;
     float h0[PF_H];
 #pragma unroll
     for (int u = 0; u < PF_H; u += 4) {
         const float4 v = *reinterpret_cast<const float4*>(hp + u);
         h0[u] = v.x; h0[u + 1] = v.y; h0[u + 2] = v.z; h0[u + 3] = v.w;
     }
-    const float p0 = a_.p[slot * PF_P + pl];
+    const float p0 = a_.p[slot * PF_P + q];
     float x[PF_IN];
     {
-        cmem_t o = as_cmem(a_.obs + ((size_t)n * a_.A + own) * RS_OBS_DIM);
+        const float* o = a_.obs + ((size_t)n * a_.A + own) * RS_OBS_DIM;
 #pragma unroll
         for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
     }
@@ -150,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
         const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n]) * 8ull;
         const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
         k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
-        pk = k_eps * 1048583ull + (uint64_t)pl * 4096ull;
+        pk = k_eps * 1048583ull + (uint64_t)q * 4096ull;
     }
 
     // ---- gates: z | r = sigmoid(W_zr [h0, x] + b)
@@ -166,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
     for (int u = 0; u < PF_H; ++u) {
         float eps;
         if constexpr (REC) {
-            eps = a_.eps_in[(slot * PF_P + pl) * PF_H + u];
+            eps = a_.eps_in[(slot * PF_P + q) * PF_H + u];
         } else {
             const uint64_t hx = pf_hash(pk + (uint64_t)u);
             const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
@@ -181,68 +178,91 @@ __global__ void __launch_bounds__(256, 2) rs_pfgru_kernel(PfArgs a_) {
         const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
         h1[u] = (1.0f - g[u]) * nv + g[u] * h0[u];
     }
-    // ---- observation likelihood, log-softmax over the particles
+    // ---- observation likelihood, log-softmax over the set's particles
     float lg = W[PF_OB];
 #pragma unroll
     for (int k = 0; k < PF_K; ++k) lg = fmaf(W[PF_O + k], (k < PF_H) ? h1[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H], lg);
     lg += p0;
-    const float mx = wave_max(act ? lg : -INFINITY);
-    const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
-    float p1 = (lg - mx) - logf(se);
+    if (act) va[q] = lg;
+    __syncthreads();                                                // 1
+    const float mx = pk_max40(va);
+    const float e1 = expf(lg - mx);
+    if (act) vb[q] = e1;
+    __syncthreads();                                                // 2
+    float p1 = (lg - mx) - logf(pk_sum40(vb));
     // ---- soft resampling: indices by inverse CDF of alpha * w + (1 - alpha) / P
     const float al = a_.alpha, floor_ = a_.floor_;
-    {
-        double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
-        c = rs_wave_scan(c);                                       // inclusive scan over the lanes (float64) on the DPP path
-        const double tot = rs_lane_d<PF_P - 1>(c);
-        if (act) cdf[lane] = c / tot;
+    if (act) {
+        va[q] = al * expf(p1) + floor_;
+        vc[q] = p1;
 #pragma unroll
-        for (int u = 0; u < PF_H; ++u) if (act) tile[lane * PF_ROW + u] = h1[u];
-        vec[lane] = p1;
+        for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = h1[u];
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();                                                // 3
     int idx = 0;
     if constexpr (REC) {
-        idx = min(max(a_.idx_in[slot * PF_P + pl], 0), PF_P - 1);
+        idx = min(max(a_.idx_in[slot * PF_P + q], 0), PF_P - 1);
     } else {
-        const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)pl * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
-        for (int q = 0; q < PF_P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;  // searchsorted(..., right=True)
+        double run = 0.0, mine = 0.0;                               // float64 prefix sums in index order (torch.cumsum of the .double() weights)
+#pragma unroll
+        for (int i = 0; i < PF_P / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(va)[i];
+            run += (double)t.x; mine = (4 * i == q) ? run : mine;
+            run += (double)t.y; mine = (4 * i + 1 == q) ? run : mine;
+            run += (double)t.z; mine = (4 * i + 2 == q) ? run : mine;
+            run += (double)t.w; mine = (4 * i + 3 == q) ? run : mine;
+        }
+        if (act) cdf[q] = mine / run;
+        __syncthreads();                                            // 4
+        const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)q * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
+#pragma unroll
+        for (int j = 0; j < PF_P / 2; ++j) {                        // searchsorted(..., right=True)
+            const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
+            idx += (c2.x <= ru) ? 1 : 0;
+            idx += (c2.y <= ru) ? 1 : 0;
+        }
         idx = min(idx, PF_P - 1);
     }
 #pragma unroll
     for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
-    float pn = expf(vec[idx]);
+    float pn = expf(vc[idx]);
     pn = logf(pn / (al * pn + floor_));
-    const float mx2 = wave_max(act ? pn : -INFINITY);
-    const float lse = logf(wave_sum(act ? expf(pn - mx2) : 0.0f)) + mx2;
-    p1 = pn - lse;
-    if (a_.carry && (a_.mask == nullptr || a_.mask[n]) && act) {
-        float* hw = a_.h + (slot * PF_P + lane) * PF_H;
+    if (act) vb[q] = pn;
+    __syncthreads();                                                // 5
+    const float mx2 = pk_max40(vb);
+    const float e2 = expf(pn - mx2);
+    if (act) va[q] = e2;
+    __syncthreads();                                                // 6
+    p1 = pn - (logf(pk_sum40(va)) + mx2);
+    if (a_.carry && live) {
+        float* hw = a_.h + (slot * PF_P + q) * PF_H;
 #pragma unroll
         for (int u = 0; u < PF_H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
-        a_.p[slot * PF_P + lane] = p1;
+        a_.p[slot * PF_P + q] = p1;
     }
     // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
-    __builtin_amdgcn_wave_barrier();
     const float wgt = expf(p1);
+    if (act) {
 #pragma unroll
-    for (int u = 0; u < PF_H; ++u) if (act) tile[lane * PF_ROW + u] = wgt * h1[u];
-    __builtin_amdgcn_wave_barrier();
-    const int ul = lane < PF_H ? lane : PF_H - 1;
+        for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = wgt * h1[u];      // every lane gathered its row before barrier 5
+    }
+    __syncthreads();                                                // 7
+    const int ul = q < PF_H ? q : PF_H - 1;
     float mean = 0.0f;
-    for (int q = 0; q < PF_P; ++q) mean += tile[q * PF_ROW + ul];
-    __builtin_amdgcn_wave_barrier();
-    vec[lane] = mean;                                              // lanes 0..23: mean_hid[lane]
-    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < PF_P; ++j) mean += tile[j * PF_ROW + ul];
+    if (act && q < PF_H) vm[q] = mean;
+    __syncthreads();                                                // 8
     const float* wg = a_.w + (size_t)own * PF_STRIDE;
     float t = wg[PF_H0B + ul];
-    for (int k = 0; k < PF_H; ++k) t = fmaf(wg[PF_H0 + k * 24 + ul], vec[k], t);
+    for (int k = 0; k < PF_H; ++k) t = fmaf(wg[PF_H0 + k * 24 + ul], vm[k], t);
     t = fmaxf(t, 0.0f);
-    const float o0 = wave_sum(lane < PF_H ? wg[PF_H2 + ul] * t : 0.0f) + wg[PF_H2B];
-    const float o1 = wave_sum(lane < PF_H ? wg[PF_H2 + 24 + ul] * t : 0.0f) + wg[PF_H2B + 1];
-    if (lane == 0) {
+    if (act && q < PF_H) { vb[q] = wg[PF_H2 + ul] * t; vc[q] = wg[PF_H2 + 24 + ul] * t; }      // vb / vc: last read before barrier 6
+    __syncthreads();                                                // 9
+    if (live && q == 0) {
+        float o0 = 0.0f, o1 = 0.0f;
+        for (int k = 0; k < PF_H; ++k) { o0 += vb[k]; o1 += vc[k]; }
         float* out = a_.pred + ((size_t)n * a_.A + own) * 2;
-        out[0] = fmaxf(o0, 0.0f); out[1] = fmaxf(o1, 0.0f);
+        out[0] = fmaxf(o0 + wg[PF_H2B], 0.0f); out[1] = fmaxf(o1 + wg[PF_H2B + 1], 0.0f);
     }
 }
 
@@ -334,9 +354,8 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
         return RS_ERR_INVALID_ARG;
     PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
-    const long long waves = (long long)num_envs * num_agents;
-    hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
-                       static_cast<hipStream_t>(stream), a);
+    const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
+    hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
@@ -346,9 +365,8 @@ int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, flo
     if (!weights || !obs || !h || !p || !eps || !idx || !pred || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
     PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
-    const long long waves = (long long)num_envs * num_agents;
-    hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 4 * PF_LDS_WAVE,
-                       static_cast<hipStream_t>(stream), a);
+    const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
+    hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
