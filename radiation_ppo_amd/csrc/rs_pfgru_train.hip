@@ -82,30 +82,50 @@ __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__b
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 
 // gates and candidate state of one particle: z, r, n, es = eps * d softplus(var) / d var, h1 = (1 - z) n + z h0, lg = fc_obs([h1, x])
-__device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const float (&x)[IN], const float (&eps)[H], float (&z)[H],
-                                        float (&r)[H], float (&n)[H], float (&es)[H], float (&h1)[H], float& lg) {
+// One step of the cell for the forward walk: h1 and the observation logit; the gates z | r | n | eps * softplus'(var) go straight to
+// `gw` (what the backward walk reloads: 384 B per particle instead of recomputing both gate products and their transcendentals, which
+// was 21 % of the fused kernel) as soon as they exist, so that only z and r * h0 stay live across the second product.
+__device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const float (&x)[IN], const float (&eps)[H], float4* gw, bool store,
+                                        float (&h1)[H], float& lg) {
     float g[48];
 #pragma unroll
     for (int o = 0; o < 48; ++o) g[o] = W[T_ZRB + o];
     mv<28, 48>(W + T_ZR, [&](int k) -> float { return k < H ? h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, g);
+    float z[H], rh[H];
 #pragma unroll
-    for (int u = 0; u < H; ++u) { z[u] = sigmoidf_(g[u]); r[u] = sigmoidf_(g[H + u]); }
+    for (int u = 0; u < H; u += 4) {
+        float r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { z[u + j] = sigmoidf_(g[u + j]); r4[j] = sigmoidf_(g[H + u + j]); rh[u + j] = r4[j] * h0[u + j]; }
+        if (store) {
+            gw[u / 4] = make_float4(z[u], z[u + 1], z[u + 2], z[u + 3]);
+            gw[6 + u / 4] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        }
+    }
     float m[48];
 #pragma unroll
     for (int o = 0; o < 48; ++o) m[o] = W[T_NB + o];
-    mv<28, 48>(W + T_N, [&](int k) -> float { return k < H ? r[k < H ? k : 0] * h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, m);
+    mv<28, 48>(W + T_N, [&](int k) -> float { return k < H ? rh[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, m);
     lg = W[T_O + 27];
 #pragma unroll
-    for (int u = 0; u < H; ++u) {
-        const float var = m[H + u];
-        const float e = __builtin_amdgcn_exp2f(1.44269504f * var);
-        const bool big = var > 20.0f;                                                // F.softplus: identity (slope 1) beyond 20
-        const float sp = big ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + e);
-        es[u] = big ? eps[u] : eps[u] * (1.0f - __builtin_amdgcn_rcpf(1.0f + e));
-        const float y = m[u] + eps[u] * sp;
-        n[u] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));      // tanh
-        h1[u] = (1.0f - z[u]) * n[u] + z[u] * h0[u];
-        lg = fmaf(W[T_O + u], h1[u], lg);
+    for (int u = 0; u < H; u += 4) {
+        float n4[4], es4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float var = m[H + u + j];
+            const float e = __builtin_amdgcn_exp2f(1.44269504f * var);
+            const bool big = var > 20.0f;                                                // F.softplus: identity (slope 1) beyond 20
+            const float sp = big ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + e);
+            es4[j] = big ? eps[u + j] : eps[u + j] * (1.0f - __builtin_amdgcn_rcpf(1.0f + e));
+            const float y = m[u + j] + eps[u + j] * sp;
+            n4[j] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));      // tanh
+            h1[u + j] = (1.0f - z[u + j]) * n4[j] + z[u + j] * h0[u + j];
+            lg = fmaf(W[T_O + u + j], h1[u + j], lg);
+        }
+        if (store) {
+            gw[12 + u / 4] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+            gw[18 + u / 4] = make_float4(es4[0], es4[1], es4[2], es4[3]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < IN; ++k) lg = fmaf(W[T_O + H + k], x[k], lg);
@@ -172,22 +192,57 @@ __device__ __forceinline__ void outer_store(const f4 (&acc)[TI][TJ], float* out,
 
 // The forward walk of a training pass as its own launch (round 3).  Inside the 512-register backward kernel it ran at one wave per SIMD,
 // where a lone wave issues a VALU instruction only every ~5 cycles (scripts/micro/sload_latency.hip: 32 v_fmac = 180 cycles; two or
-// more waves share the SIMD at 2.5): the walk needs no gradient accumulators, fits 2 waves per SIMD without spilling (3 waves: 33 registers spilled) and stores everything the backward
-// walk reads (particle sets, log-weights, resampling indices, gates) exactly as the fused kernel did.
-constexpr int FWD_LDS_FLOATS = TILE_F + 2 * P + 64;
-__global__ void __launch_bounds__(64, 2) rs_pfgru_train_fwd_kernel(TrArgs a_) {
-    __shared__ __align__(16) float smem[FWD_LDS_FLOATS];
-    const int lane = threadIdx.x;
-    const int e = blockIdx.x;
-    float* tile = smem;                                              // [44][ROW]
-    double* cdf = reinterpret_cast<double*>(smem + TILE_F);          // [P]
-    float* vec = smem + TILE_F + 2 * P;                              // [64]
-    const bool act = lane < P;
-    const int pl = act ? lane : P - 1;                               // idle lanes shadow the last particle (values discarded)
+// more waves share the SIMD at 2.5): the walk needs no gradient accumulators, fits 2 waves per SIMD without spilling (175 VGPRs; at 3 waves 9
+// registers spill and the pass is no faster: 16.9 against 16.5 ms for 16 384 episodes) and stores everything the backward walk reads (particle sets, log-weights, resampling indices, gates) exactly as
+// the fused kernel did.  Lane-packed like K11 (csrc/rs_pfgru.hip): six episodes of 40 particles per 256-thread workgroup, what couples
+// an episode's particles goes through LDS and workgroup barriers, every lane reducing its episode's 40 values in index order.
+constexpr int FW_SETS = 6, FW_NT = 256;
+constexpr int FW_TILE = 0, FW_CDF = P * ROW, FW_VA = FW_CDF + 2 * P, FW_VB = FW_VA + P, FW_VC = FW_VB + P, FW_STRIDE = 1228;
+static_assert(FW_VC + P <= FW_STRIDE && FW_STRIDE % 4 == 0 && FW_STRIDE % 32 == 12 && FW_CDF % 2 == 0, "LDS layout of an episode's particle set");
+
+__device__ __forceinline__ float fw_max40(const float* v) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < P / 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(v)[i];
+        m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+    }
+    return m;
+}
+__device__ __forceinline__ float fw_sum40(const float* v) {          // index order
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < P / 4; ++i) {
+        const float4 t = reinterpret_cast<const float4*>(v)[i];
+        s = (((s + t.x) + t.y) + t.z) + t.w;
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(FW_NT, 2) rs_pfgru_train_fwd_kernel(TrArgs a_) {
+    __shared__ __align__(16) float smem[FW_SETS * FW_STRIDE];
+    __shared__ int lens_s[FW_SETS];
+    const int tid = threadIdx.x;
+    const int set = tid / P, q = tid - set * P;                       // set == FW_SETS: the 16 lanes that carry nothing
+    const int E = a_.E;
+    const int e_raw = blockIdx.x * FW_SETS + set;
+    const bool has = set < FW_SETS && e_raw < E;
+    const int e = has ? e_raw : E - 1;                                // lanes without an episode shadow the last one (nothing is stored)
+    const int len = has ? (int)a_.lens[e] : 0;
+    if (tid < FW_SETS) lens_s[tid] = 0;
+    __syncthreads();
+    if (has && q == 0) lens_s[set] = len;
+    __syncthreads();
+    int lmax = 0;
+#pragma unroll
+    for (int i = 0; i < FW_SETS; ++i) lmax = max(lmax, lens_s[i]);   // the workgroup walks to its longest episode (sorted batches: equal lengths)
+    float* S = smem + (set < FW_SETS ? set : FW_SETS - 1) * FW_STRIDE;
+    float* tile = S + FW_TILE;
+    double* cdf = reinterpret_cast<double*>(S + FW_CDF);
+    float *va = S + FW_VA, *vb = S + FW_VB, *vc = S + FW_VC;
+    const bool act = set < FW_SETS;                                   // LDS writes allowed (the set's own area)
     K13_DECL
     auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
-    const int E = a_.E;
-    const int len = (int)a_.lens[e];
     const float al = a_.alpha, floor_ = a_.floor_;
     const size_t PH = (size_t)P * H;
     auto load24 = [&](const float* src, float (&dst)[H]) {
@@ -197,74 +252,83 @@ __global__ void __launch_bounds__(64, 2) rs_pfgru_train_fwd_kernel(TrArgs a_) {
             dst[u] = v.x; dst[u + 1] = v.y; dst[u + 2] = v.z; dst[u + 3] = v.w;
         }
     };
-    auto load_x = [&](int t, float (&x)[IN]) {
-        const cmem_t o = as_cmem(a_.obs + ((size_t)t * E + e) * RS_OBS_DIM);
+    float h0[H];
+    load24(a_.h0 + ((size_t)e * P + q) * H, h0);
+    float p0 = -3.6888794541139363f;                                 // float32(log(1 / 40))
+    for (int t = 0; t < lmax; ++t) {
+        const bool on = t < len;                                      // this episode is still running (uniform over its 40 lanes)
+        const int tc = on ? t : (len > 0 ? len - 1 : 0);              // finished episodes re-read their last step (nothing is stored)
+        const cmem_t W = wptr();
+        const size_t te = (size_t)tc * E + e;
+        float x[IN], eps[H], h1[H], lg;
+        {
+            const float* o = a_.obs + te * RS_OBS_DIM;
 #pragma unroll
-        for (int k = 0; k < IN; ++k) x[k] = o[k];
-    };
-    {
-        float h0[H];
-        load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
-        float p0 = -3.6888794541139363f;                             // float32(log(1 / 40))
-        for (int t = 0; t < len; ++t) {
-            const cmem_t W = wptr();
-            const size_t te = (size_t)t * E + e;
-            float x[IN], eps[H], z[H], r[H], n[H], es[H], h1[H], lg;
-            load_x(t, x);
-            load24(a_.eps + te * PH + (size_t)pl * H, eps);
-            pf_cell(W, h0, x, eps, z, r, n, es, h1, lg);
-            if (act) {
-                // what the backward walk needs of this step besides the particle sets: 384 B per particle instead of recomputing both
-                // gate products and their transcendentals (phase stamps: the recomputation was 21 % of the kernel)
-                float4* gw = reinterpret_cast<float4*>(a_.gates + (te * P + lane) * (size_t)(4 * H));
-#pragma unroll
-                for (int u = 0; u < H; u += 4) {
-                    gw[u / 4] = make_float4(z[u], z[u + 1], z[u + 2], z[u + 3]);
-                    gw[6 + u / 4] = make_float4(r[u], r[u + 1], r[u + 2], r[u + 3]);
-                    gw[12 + u / 4] = make_float4(n[u], n[u + 1], n[u + 2], n[u + 3]);
-                    gw[18 + u / 4] = make_float4(es[u], es[u + 1], es[u + 2], es[u + 3]);
-                }
-            }
-            K13_STAMP(0)                                             // forward: loads + cell
-            lg += p0;
-            const float mx = wave_max(act ? lg : -INFINITY);
-            const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
-            const float p1 = (lg - mx) - logf(se);
-            double c = act ? (double)(al * expf(p1) + floor_) : 0.0;
-            c = rs_wave_scan(c);                                       // inclusive scan over the lanes (float64) on the DPP path
-            const double tot = rs_lane_d<P - 1>(c);
-            if (act) cdf[lane] = c / tot;
-#pragma unroll
-            for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = h1[u];
-            vec[lane] = p1;
-            __builtin_amdgcn_wave_barrier();
-            int idx = 0;
-            if (a_.u) {
-                const double ru = a_.u[te * P + pl];
-                for (int q = 0; q < P; ++q) idx += (cdf[q] <= ru) ? 1 : 0;   // searchsorted(..., right=True)
-                idx = min(idx, P - 1);
-            } else {
-                idx = min(max(a_.idx[te * P + pl], 0), P - 1);          // what torch.multinomial returned in the reference's run
-            }
-#pragma unroll
-            for (int u = 0; u < H; ++u) h0[u] = tile[idx * ROW + u];
-            float pn = expf(vec[idx]);
-            pn = logf(pn / (al * pn + floor_));
-            const float mx2 = wave_max(act ? pn : -INFINITY);
-            const float lse = logf(wave_sum(act ? expf(pn - mx2) : 0.0f)) + mx2;
-            p0 = pn - lse;
-            __builtin_amdgcn_wave_barrier();
-            if (act) {
-                float* hw = a_.hs + te * PH + (size_t)lane * H;
-#pragma unroll
-                for (int u = 0; u < H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
-                a_.ps[te * P + lane] = p0;
-                a_.idx[te * P + lane] = idx;
-            }
-            K13_STAMP(1)                                             // forward: softmax, resampling, stores
+            for (int k = 0; k < IN; ++k) x[k] = o[k];
         }
+        load24(a_.eps + te * PH + (size_t)q * H, eps);
+        pf_cell(W, h0, x, eps, reinterpret_cast<float4*>(a_.gates + (te * P + q) * (size_t)(4 * H)), on, h1, lg);
+        K13_STAMP(0)                                                 // forward: loads + cell
+        lg += p0;
+        if (act) va[q] = lg;
+        __syncthreads();                                             // 1
+        const float mx = fw_max40(va);
+        const float e1 = expf(lg - mx);
+        if (act) vb[q] = e1;
+        __syncthreads();                                             // 2
+        const float p1 = (lg - mx) - logf(fw_sum40(vb));
+        if (act) {
+            va[q] = al * expf(p1) + floor_;
+            vc[q] = p1;
+#pragma unroll
+            for (int u = 0; u < H; ++u) tile[q * ROW + u] = h1[u];
+        }
+        __syncthreads();                                             // 3
+        int idx = 0;
+        if (a_.u) {
+            double run = 0.0, mine = 0.0;                            // float64 prefix sums in index order
+#pragma unroll
+            for (int i = 0; i < P / 4; ++i) {
+                const float4 w4 = reinterpret_cast<const float4*>(va)[i];
+                run += (double)w4.x; mine = (4 * i == q) ? run : mine;
+                run += (double)w4.y; mine = (4 * i + 1 == q) ? run : mine;
+                run += (double)w4.z; mine = (4 * i + 2 == q) ? run : mine;
+                run += (double)w4.w; mine = (4 * i + 3 == q) ? run : mine;
+            }
+            if (act) cdf[q] = mine / run;
+            __syncthreads();                                         // 4 (a_.u is a launch argument: every lane takes this branch or none)
+            const double ru = a_.u[te * P + q];
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) {                        // searchsorted(..., right=True)
+                const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
+                idx += (c2.x <= ru) ? 1 : 0;
+                idx += (c2.y <= ru) ? 1 : 0;
+            }
+            idx = min(idx, P - 1);
+        } else {
+            idx = min(max(a_.idx[te * P + q], 0), P - 1);            // what torch.multinomial returned in the reference's run
+        }
+#pragma unroll
+        for (int u = 0; u < H; ++u) h0[u] = tile[idx * ROW + u];
+        float pn = expf(vc[idx]);
+        pn = logf(pn / (al * pn + floor_));
+        if (act) vb[q] = pn;
+        __syncthreads();                                             // 5
+        const float mx2 = fw_max40(vb);
+        const float e2 = expf(pn - mx2);
+        if (act) va[q] = e2;
+        __syncthreads();                                             // 6
+        p0 = pn - (logf(fw_sum40(va)) + mx2);
+        if (on) {
+            float* hw = a_.hs + te * PH + (size_t)q * H;
+#pragma unroll
+            for (int u = 0; u < H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
+            a_.ps[te * P + q] = p0;
+            a_.idx[te * P + q] = idx;
+        }
+        __syncthreads();                                             // 7: va / tile are rewritten at the top of the next step
+        K13_STAMP(1)                                                 // forward: softmax, resampling, stores
     }
-
     K13_FLUSH
 }
 
@@ -610,7 +674,7 @@ int rs_pfgru_train(const float* weights, const float* obs, const float* target, 
         return RS_ERR_INVALID_ARG;
     TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
              (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
-    hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel, dim3((unsigned)((episodes + FW_SETS - 1) / FW_SETS)), dim3(FW_NT), 0, static_cast<hipStream_t>(stream), a);
     hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
