@@ -324,6 +324,13 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
 int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
                   const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
                   int32_t num_agents, rs_stream_t stream);
+/* A whole no-grad pass over an episode-major batch in ONE call: grad_step's PFGRU loop over an episode (RADA2C_core.py:555-558) for E
+ * episodes of one predictor.  Enqueues rs_pfgru_reset and then one rs_pfgru_step per time step t < steps on `stream` (carried particle
+ * sets, the step counter of launch t = calls[t][.]), each over the first alive[t] episodes (episodes sorted by descending length: the ones
+ * still running are a prefix).  obs [steps][E][11], calls [steps][E], pred [steps][E][2], alive: HOST array [steps].  Exists so that the
+ * ~120 launches of a pass cost one library call: the policy loop of update_rada2c issues 40 such passes per update. */
+int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
+                  const int64_t* calls, double alpha, float* pred, const int32_t* alive, int32_t steps, int32_t episodes, rs_stream_t stream);
 /* The same step with the draws supplied instead of hashed: eps [A][N][40][24] = the reparameterisation noise, idx [A][N][40] = the
  * resampling indices (what FloatTensor.normal_ / torch.multinomial returned in a recorded run of the reference, :1485-1530).  The
  * arithmetic is the product kernel's (one template, two instantiations); used to hold it to tests/golden/pfgru.npz directly. */

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("rs_pfgru_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_pfgru_step_recorded", C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("rs_pfgru_pass", C.c_int, [C.c_void_p] * 7 + [C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_pfgru_reset", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                  C.c_void_p]),
     ("rs_pfgru_draws", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

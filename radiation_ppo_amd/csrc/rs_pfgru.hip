@@ -359,6 +359,18 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
+int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
+                  const int64_t* calls, double alpha, float* pred, const int32_t* alive, int32_t steps, int32_t episodes, rs_stream_t stream) {
+    if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || !alive || steps < 1 || episodes < 1) return RS_ERR_INVALID_ARG;
+    for (int t = 0; t < steps; ++t)
+        if (alive[t] < 0 || alive[t] > episodes || (t > 0 && alive[t] > alive[t - 1])) return RS_ERR_INVALID_ARG;
+    int rc = rs_pfgru_reset(h, p, base_key, episode, calls, nullptr, episodes, 1, stream);
+    for (int t = 0; t < steps && rc == RS_OK && alive[t] > 0; ++t)
+        rc = rs_pfgru_step(weights, obs + (size_t)t * episodes * RS_OBS_DIM, h, p, base_key, episode, calls + (size_t)t * episodes, nullptr, 1, alpha,
+                           pred + (size_t)t * episodes * 2, alive[t], 1, stream);
+    return rc;
+}
+
 int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, float* p, const float* eps, const int32_t* idx,
                            const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
                            rs_stream_t stream) {

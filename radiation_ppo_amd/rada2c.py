@@ -565,13 +565,12 @@ class RNNAgentPPO:
         if lens_host is not None and all(a >= b for a, b in zip(lens_host, lens_host[1:])):
             asc = lens_host[::-1]
             alive = [E - bisect.bisect_right(asc, t) for t in range(L)]
-        _lib.check(lib.rs_pfgru_reset(h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls[0].data_ptr(), None, E, 1, st),
-                   "rs_pfgru_reset")
+        # the reset and the L step launches of the pass go out from ONE library call: the policy loop issues 40 passes per update, and
+        # ~120 ctypes calls per pass made it host-bound on a busy box (46 ms per policy iteration against 14 ms of kernels)
         Xc = X.contiguous()
-        for t in range(L):
-            _lib.check(lib.rs_pfgru_step(wts.data_ptr(), Xc[t].data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(),
-                                         calls[t].data_ptr(), None, 1, float(self.agent.model.resamp_alpha), loc[t].data_ptr(), alive[t], 1, st),
-                       "rs_pfgru_step")
+        alive_h = (C.c_int32 * L)(*alive)
+        _lib.check(lib.rs_pfgru_pass(wts.data_ptr(), Xc.data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(),
+                                     float(self.agent.model.resamp_alpha), loc.data_ptr(), alive_h, L, E, st), "rs_pfgru_pass")
         return loc
 
     def _pfgru_pass_hip_recorded(self, X: torch.Tensor, draws: "RecordedKernelDraws") -> torch.Tensor:
