@@ -440,13 +440,14 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     torch.cuda.synchronize()
     _lib.EVENTS = {}
     tc = tu = 0.0
-    stops = []
+    stops, loops = [], []
     t0 = time.perf_counter()
     for _ in range(iters):
         a = time.perf_counter(); col.collect(); torch.cuda.synchronize(); b = time.perf_counter()
         res = col.update(); torch.cuda.synchronize(); c = time.perf_counter()
         tc += b - a; tu += c - b
         stops.append(res[0].stop_iteration)
+        loops.append(1e3 * getattr(ag[0], "policy_loop_seconds", 0.0))
     dt = time.perf_counter() - t0
     ev, _lib.EVENTS = _lib.EVENTS, None
     out = {"workload": "single-agent RAD-A2C (GRU(13->24) actor-critic + PFGRU predictor, 40 particles), U{1..5} random rectangles, "
@@ -456,6 +457,11 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
            "policy_iterations": stops, "pfgru_iterations": ag[0].train_pfgru_iters, "env_error_flags": env.error_flags(),
            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+    # where an update's time goes: the K13 passes (events), the policy loop's wall time, and the K11 passes of the policy iterations
+    # as the GPU saw them (events on the side stream: ~13.7 ms each; a policy iteration cannot be shorter than its pass)
+    kp = _ms(ev.get("rs_pfgru_pass", []))
+    out["update_split_ms"] = {"k13_passes": sum(_ms(ev.get("rs_pfgru_train", []))) / iters, "policy_loop_wall": sum(loops) / max(len(loops), 1),
+                              "k11_pass_gpu_mean": (sum(kp) / len(kp)) if kp else None, "k11_passes_per_update": len(kp) / iters}
     ds = _ms(ev.get("rs_pfgru_train", []))
     if ds:
         # K13: 9 561 multiply-adds per particle-step (forward cell 2 619, hid_obs forward + backward 1 248, transposed products 2 328,

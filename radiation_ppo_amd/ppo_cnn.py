@@ -23,7 +23,7 @@ from . import _lib
 from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps, actor_stack_from
 from .pfgru import PredictorBank
-from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
+from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, host_read, normalize_advantages, reduce_grads_and_stats
 
 
 class ActorLoss(torch.autograd.Function):
@@ -132,7 +132,7 @@ class CNNAgentPPO:
             # (mpi_avg_grads + mpi_avg, ppo.py:841 / :838).  The KL decision is taken on the host: an iteration here is four
             # 524 288-sample chunks through K9 / K10 (tens of milliseconds), so the one read costs nothing and a stopped loop
             # must not enqueue further passes.
-            last = reduce_grads_and_stats(self.pi.parameters(), stats).tolist()
+            last = host_read(reduce_grads_and_stats(self.pi.parameters(), stats))
             if last[0] < thr:                                                   # ppo.py:838-845
                 self.pi_optimizer.step()
             else:

@@ -30,6 +30,7 @@ loop's last episode, :1274); (iii) several agents are independent copies, each f
 import bisect
 import ctypes as C
 import math
+import time
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -41,7 +42,7 @@ import torch.nn.functional as F
 from . import _lib
 from .envs import RadSearchVec
 from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
-from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, normalize_advantages, reduce_grads_and_stats
+from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, host_read, normalize_advantages, reduce_grads_and_stats
 
 
 def _mlp_tanh(sizes) -> nn.Sequential:
@@ -265,16 +266,45 @@ class HashDraws:
         return dict(resample_u=hash_uniform(self._key(2, t).view(-1, 1) * 1048583 + self._pu[:, 0].unsqueeze(0)))
 
 
+class Scratch:
+    """Persistent device scratch for the buffers of an update whose size follows the epoch's episode count, which moves by a fraction
+    of a percent from epoch to epoch.  A buffer is kept, grown with 1/8 headroom when too small, and handed out as a view.  Left to
+    torch's caching allocator, a request slightly larger than last epoch's multi-GB block is met by a fresh hipMalloc (hundreds of
+    milliseconds for K13's 30 GB of gates) while the old block stays reserved: the RAD-A2C update took 1.7 s or 2.3-2.7 s depending on
+    whether the epoch happened to have more episodes than any before it."""
+
+    def __init__(self):
+        self.bufs: Dict[Any, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        key = (name, dtype, str(device))
+        b = self.bufs.get(key)
+        if b is None or b.numel() < n:
+            self.bufs.pop(key, None)
+            b = None                                                         # release the old block before asking for the larger one
+            b = self.bufs[key] = torch.empty(n + n // 8, dtype=dtype, device=device)
+        return b[:n].view(*shape)
+
+
 class KernelDraws:
     """HashDraws with every draw of the pass produced by ONE launch (rs_pfgru_draws) instead of ~25 int64 element-wise launches per
-    step; same keys, same hash, same values (the normals to float32 rounding of the library log / cos)."""
+    step; same keys, same hash, same values (the normals to float32 rounding of the library log / cos).  scratch: where the draws go
+    (Scratch; the previous pass's draws are overwritten, stream ordered) -- None: fresh tensors."""
 
-    def __init__(self, keys: torch.Tensor, L: int):
+    def __init__(self, keys: torch.Tensor, L: int, scratch: Optional[Scratch] = None, tag: str = ""):
         self.k = keys.contiguous()
         E, dev = keys.shape[0], keys.device
-        self._pf = torch.empty(E, 40, 24, dtype=torch.float32, device=dev)
-        self._eps = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
-        self._u = torch.empty(L, E, 40, dtype=torch.float64, device=dev)
+        if scratch is None:
+            self._pf = torch.empty(E, 40, 24, dtype=torch.float32, device=dev)
+            self._eps = torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev)
+            self._u = torch.empty(L, E, 40, dtype=torch.float64, device=dev)
+        else:
+            self._pf = scratch.get("draws_pf" + tag, (E, 40, 24), torch.float32, dev)
+            self._eps = scratch.get("draws_eps" + tag, (L, E, 40, 24), torch.float32, dev)
+            self._u = scratch.get("draws_u" + tag, (L, E, 40), torch.float64, dev)
         _lib.check(_lib.load().rs_pfgru_draws(self.k.data_ptr(), E, L, self._pf.data_ptr(), self._eps.data_ptr(), self._u.data_ptr(),
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_draws")
 
@@ -486,6 +516,7 @@ class RNNAgentPPO:
         b = bp_args if bp_args is not None else BpArgs(area_scale=env_height)
         self.bp_args = BpArgs(*(b if isinstance(b, tuple) else (b.bp_decay, b.l2_weight, b.l1_weight, b.elbo_weight, b.area_scale)))
         self.env_height, self.seed, self.episode_chunk = float(env_height), int(seed), int(episode_chunk)
+        self.scratch = Scratch()
         args = dict(actor_critic_args or {})
         args.setdefault("obs_dim", observation_space); args.setdefault("act_dim", action_space)
         self.agent = RNNModelActorCritic(**args).to(self.device)
@@ -569,8 +600,9 @@ class RNNAgentPPO:
         # ~120 ctypes calls per pass made it host-bound on a busy box (46 ms per policy iteration against 14 ms of kernels)
         Xc = X.contiguous()
         alive_h = (C.c_int32 * L)(*alive)
-        _lib.check(lib.rs_pfgru_pass(wts.data_ptr(), Xc.data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(),
-                                     float(self.agent.model.resamp_alpha), loc.data_ptr(), alive_h, L, E, st), "rs_pfgru_pass")
+        with _lib.timed("rs_pfgru_pass"):
+            _lib.check(lib.rs_pfgru_pass(wts.data_ptr(), Xc.data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(),
+                                         float(self.agent.model.resamp_alpha), loc.data_ptr(), alive_h, L, E, st), "rs_pfgru_pass")
         return loc
 
     def _pfgru_pass_hip_recorded(self, X: torch.Tensor, draws: "RecordedKernelDraws") -> torch.Tensor:
@@ -631,9 +663,11 @@ class RNNAgentPPO:
             tt = torch.arange(L, device=dev, dtype=torch.float64).unsqueeze(1)
             bp = torch.exp(a.bp_decay * tt) * Bc.valid.double()
             bp = (bp / bp.sum(dim=0, keepdim=True)).float().contiguous()           # :1074-1075
+            sc, tag = self.scratch, f"_{sl.start}"
+            idx0 = sc.get("k13_idx" + tag, (L, E, 40), torch.int32, dev)
+            idx0.zero_()                                                           # idx: steps beyond an episode's end are never written
             cache[ck] = (X, (Bc.src / a.area_scale).float().contiguous(), bp, Bc.lens.contiguous(), Bc.w_ep.float().contiguous(),
-                         torch.empty(L, E, 40, 24, dtype=torch.float32, device=dev), torch.empty(L, E, 40, dtype=torch.float32, device=dev),
-                         torch.zeros(L, E, 40, dtype=torch.int32, device=dev))     # idx: steps beyond an episode's end are never written
+                         sc.get("k13_hs" + tag, (L, E, 40, 24), torch.float32, dev), sc.get("k13_ps" + tag, (L, E, 40), torch.float32, dev), idx0)
         X, tar, bp, lens, w_ep, hs, ps, idx = cache[ck]
         L, E = X.shape[0], X.shape[1]
         loss = torch.empty(E, dtype=torch.float32, device=dev)
@@ -645,13 +679,11 @@ class RNNAgentPPO:
         if d._u is None:                                                           # recorded draws: idx is the kernel's INPUT
             idx.copy_(d._idx32)
         # the forward walk's gates (384 B per particle-step): one scratch buffer shared by all chunks and iterations (stream ordered)
-        need = L * E * 40 * 96
-        if getattr(self, "_k13_gates", None) is None or self._k13_gates.numel() < need:
-            self._k13_gates = torch.empty(need, dtype=torch.float32, device=dev)
+        gates = self.scratch.get("k13_gates", (L * E * 40 * 96,), torch.float32, dev)
         with _lib.timed("rs_pfgru_train"):
             _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
                                                   d._pf.data_ptr(), d._eps.data_ptr(), None if d._u is None else d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
-                                                  self._k13_gates.data_ptr(), idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
+                                                  gates.data_ptr(), idx.data_ptr(), loss.data_ptr(), slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha),
                                                   float(a.l2_weight), float(a.l1_weight), float(a.elbo_weight),
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
         return loss.double().sum(), slab.sum(dim=0), idx
@@ -670,7 +702,7 @@ class RNNAgentPPO:
                 if draws_for is not None:
                     d = draws_for(it, sl)
                 elif self.device.type == "cuda" and self.agent.fused_pfgru:
-                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0])
+                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0], scratch=self.scratch, tag=f"_{lo}")
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it, H=self.agent.rec, hid=self.agent.hid)
                 if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
@@ -786,7 +818,7 @@ class RNNAgentPPO:
             stats += st
         # mpi_avg(kl) (:1250) and mpi_avg_grads (:1256) in ONE collective: the statistics ride behind the gradients; the KL decision
         # is one host read per policy iteration (a stopped loop must not enqueue another pass over every episode)
-        s = reduce_grads_and_stats(self.agent.pi.parameters(), stats).tolist()
+        s = host_read(reduce_grads_and_stats(self.agent.pi.parameters(), stats))
         if s[0] < 1.5 * self.target_kl:
             self.pi_optimizer.step()
             return s, False
@@ -800,6 +832,7 @@ class RNNAgentPPO:
         kk, term, s = 0, False, None
         ahead = self.device.type == "cuda" and self.agent.fused_pfgru and getattr(self, "use_prefetch", True)
         nxt = self.loc_prefetch(B, 0) if ahead else None
+        t_loop = time.perf_counter()
         while not term and kk < self.train_pi_iters:
             cur = nxt
             if ahead:
@@ -808,6 +841,7 @@ class RNNAgentPPO:
                 torch.cuda.current_stream(self.device).wait_event(cur[1])
             s, term = self.update_rada2c(B, kk, locs=cur[0] if ahead else None)
             kk += 1
+        self.policy_loop_seconds = time.perf_counter() - t_loop              # wall time of the loop (every iteration ends in a host read)
         if ahead:
             torch.cuda.current_stream(self.device).wait_stream(self._side)   # a pass enqueued for an iteration the KL stop cancelled
         self.pi_scheduler.step(); self.pfgru_scheduler.step()
