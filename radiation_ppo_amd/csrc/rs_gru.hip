@@ -28,8 +28,8 @@ typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 
 // out[OUTP] += W^T c through the scalar-unit weight stream (csrc/rs_sstream.hpp: wait -> request -> FMA blocks of two rows)
-template <int K, int OUTP, typename F>
-__device__ __forceinline__ void gru_matvec(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
+template <int K, int OUTP, int OUTR = OUTP, typename F>
+__device__ __forceinline__ void gru_matvec(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP, OUTR>(W, cval, out); }
 
 // sigmoid / tanh on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each), branch free
 __device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(64) rs_gru_fwd_kernel(const float* __restrict_
         float gh[80];
 #pragma unroll
         for (int o = 0; o < 80; ++o) gh[o] = B[o];
-        gru_matvec<GH, 80>(W, [&](int k) -> float { return h[k]; }, gh);
+        gru_matvec<GH, 80, G3>(W, [&](int k) -> float { return h[k]; }, gh);              // 72 of the 80 columns are real
         float go[4 * GH];
 #pragma unroll
         for (int j = 0; j < GH; ++j) {
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) rs_gru_bwd_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int j = GH; j < 32; ++j) nxt[j] = 0.0f;
-        gru_matvec<G3, 32>(W, [&](int k) -> float { return dg[k]; }, nxt);       // + W_hh^T dgh
+        gru_matvec<G3, 32, GH>(W, [&](int k) -> float { return dg[k]; }, nxt);       // + W_hh^T dgh
 #pragma unroll
         for (int j = 0; j < GH; ++j) dh[j] = nxt[j];
         if (t > 0) {

@@ -70,10 +70,10 @@ __device__ __forceinline__ float wave_max(float v) { return rs_wave_max(v); }   
 __device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
 
 // The scalar-unit weight streams (wait -> request -> FMA blocks): csrc/rs_sstream.hpp
-template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
-template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) { rs_ss_mvt<K, OUTP>(W, cval, out); }
+template <int K, int OUTP, int OUTR = OUTP, typename F>
+__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP, OUTR>(W, cval, out); }
+template <int K, int OUTP, int OUTR = OUTP, typename F>
+__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) { rs_ss_mvt<K, OUTP, OUTR>(W, cval, out); }
 
 // value of lane L (a constant) in every lane: v_readlane_b32 (one instruction into an SGPR) instead of __shfl's LDS permute
 template <int L>
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float uu[32];
 #pragma unroll
         for (int o = 0; o < 32; ++o) uu[o] = W[T_H0B + o];
-        mv<H, 32>(W + T_H0, [&](int k) -> float { return v[k]; }, uu);
+        mv<H, 32, H>(W + T_H0, [&](int k) -> float { return v[k]; }, uu);             // 24 of the 32 columns are real: 16 + 8
         float out[2] = {W[T_H2 + 48], W[T_H2 + 49]};
 #pragma unroll
         for (int k = 0; k < H; ++k) {
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float dv[H];
 #pragma unroll
         for (int o = 0; o < H; ++o) dv[o] = 0.0f;
-        mvt<H, 32>(wptr() + T_H0, [&](int o) -> float { return o < H ? du[o < H ? o : 0] : 0.0f; }, dv);
+        mvt<H, 32, H>(wptr() + T_H0, [&](int o) -> float { return du[o < H ? o : 0]; }, dv);
         if (stage) {
 #pragma unroll
             for (int k = 0; k < H; ++k) { DT[k * SP + lane] = act41 ? du[k] : 0.0f; IT[k * SP + lane] = act41 ? v[k] : 0.0f; }

@@ -37,8 +37,8 @@ typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 
 // out[OUTP] += W^T c through the scalar-unit weight stream (csrc/rs_sstream.hpp: wait -> request -> FMA blocks of two rows)
-template <int K, int OUTP, typename F>
-__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP>(W, cval, out); }
+template <int K, int OUTP, int OUTR = OUTP, typename F>
+__device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP, OUTR>(W, cval, out); }
 
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float tanh_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x)); }
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     float gi[80], gh[80];
 #pragma unroll
     for (int o = 0; o < 80; ++o) { gi[o] = W[P_BIH + o]; gh[o] = W[P_BHH + o]; }
-    mv<NX, 80>(W + P_IH, [&](int k) -> float { return x[k]; }, gi);
-    mv<GH, 80>(W + P_HH, [&](int k) -> float { return h[k]; }, gh);
+    mv<NX, 80, 72>(W + P_IH, [&](int k) -> float { return x[k]; }, gi);             // 72 of the 80 columns are real
+    mv<GH, 80, 72>(W + P_HH, [&](int k) -> float { return h[k]; }, gh);
 #pragma unroll
     for (int j = 0; j < GH; ++j) {
         const float r = sigm(gi[j] + gh[j]);
