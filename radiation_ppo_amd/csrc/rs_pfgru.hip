@@ -52,7 +52,7 @@ template <int WOFF, int BOFF, typename F>
 __device__ __forceinline__ void pf_matvec48(cmem_t W, F cval, float (&out)[48]) {
 #pragma unroll
     for (int o = 0; o < 48; ++o) out[o] = W[BOFF + o];
-    rs_ss_mv<PF_KP, 48>(W + WOFF, cval, out);
+    rs_ss_mv<PF_K, 48>(W + WOFF, cval, out);                       // 27 real rows: row 27 of the block is padding
 }
 
 struct PfArgs {

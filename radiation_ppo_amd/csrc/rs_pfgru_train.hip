@@ -90,7 +90,7 @@ __device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const fl
     float g[48];
 #pragma unroll
     for (int o = 0; o < 48; ++o) g[o] = W[T_ZRB + o];
-    mv<28, 48>(W + T_ZR, [&](int k) -> float { return k < H ? h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, g);
+    mv<27, 48>(W + T_ZR, [&](int k) -> float { return k < H ? h0[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, g);
     float z[H], rh[H];
 #pragma unroll
     for (int u = 0; u < H; u += 4) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const fl
     float m[48];
 #pragma unroll
     for (int o = 0; o < 48; ++o) m[o] = W[T_NB + o];
-    mv<28, 48>(W + T_N, [&](int k) -> float { return k < H ? rh[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, m);
+    mv<27, 48>(W + T_N, [&](int k) -> float { return k < H ? rh[k < H ? k : 0] : (k < H + IN ? x[(k >= H && k < H + IN) ? k - H : 0] : 0.0f); }, m);
     lg = W[T_O + 27];
 #pragma unroll
     for (int u = 0; u < H; u += 4) {
