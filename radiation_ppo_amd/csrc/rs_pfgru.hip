@@ -44,16 +44,8 @@ __device__ __forceinline__ uint64_t pf_hash(uint64_t key) {
 }
 
 
-// out[48] = b + W^T c for a [28][48] k-major weight block read through the scalar unit: the shared weight stream of K12 - K15
-// (csrc/rs_sstream.hpp: two-row blocks in wait -> request -> FMA order, accumulators pinned at every block -- pinned only at the end of
-// a chunk, the lane-packed kernel below had single output chains sunk to their use, every row spilled to VGPR lanes and restored
-// sixteen v_readlane per FMA: 10 494 of them, 530 us per step).
-template <int WOFF, int BOFF, typename F>
-__device__ __forceinline__ void pf_matvec48(cmem_t W, F cval, float (&out)[48]) {
-#pragma unroll
-    for (int o = 0; o < 48; ++o) out[o] = W[BOFF + o];
-    rs_ss_mv<PF_K, 48>(W + WOFF, cval, out);                       // 27 real rows: row 27 of the block is padding
-}
+// sigmoid on the hardware transcendentals: v_exp_f32, v_rcp_f32 (1 ulp each)
+__device__ __forceinline__ float pf_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); }
 
 struct PfArgs {
     const float* w;           // [A][PF_STRIDE]
@@ -105,7 +97,7 @@ __device__ __forceinline__ float pk_sum40(const float* v) {          // index or
 }
 
 template <bool REC>
-__global__ void __launch_bounds__(PK_NT, 3) rs_pfgru_kernel(PfArgs a_, int groups) {
+__global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int groups) {
     __shared__ __align__(16) float smem[PK_SETS * PK_STRIDE];
     const int tid = threadIdx.x;
     const int own = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)groups));       // one owner per workgroup: wave-uniform weights
@@ -150,33 +142,69 @@ __global__ void __launch_bounds__(PK_NT, 3) rs_pfgru_kernel(PfArgs a_, int group
         pk = k_eps * 1048583ull + (uint64_t)q * 4096ull;
     }
 
-    // ---- gates: z | r = sigmoid(W_zr [h0, x] + b)
-    float g[48];
-    pf_matvec48<PF_ZR, PF_ZRB>(W, [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : (k < PF_K ? x[(k >= PF_H && k < PF_K) ? k - PF_H : 0] : 0.0f); }, g);
+    // ---- gates: z | r = sigmoid(W_zr [h0, x] + b), consumed chunk by chunk (16 accumulators live, not 48: the kernel fits 4 waves
+    // per SIMD that way): z stays, r becomes r * h0 at once
+    float z[PF_H], rh[PF_H];
+    auto cv1 = [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
+    {
+        float acc[16];
 #pragma unroll
-    for (int o = 0; o < 48; ++o) g[o] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * g[o]));   // sigmoid: v_exp_f32, v_rcp_f32 (1 ulp each)
-    // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b
-    float m[48];
-    pf_matvec48<PF_N, PF_NB>(W, [&](int k) -> float { return (k < PF_H) ? g[24 + (k < PF_H ? k : 0)] * h0[k < PF_H ? k : 0] : (k < PF_K ? x[(k >= PF_H && k < PF_K) ? k - PF_H : 0] : 0.0f); }, m);
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + o];
+        rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_ZR, cv1, acc);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) z[o] = pf_sigmoid(acc[o]);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 16 + o];
+        rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_ZR, cv1, acc);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { z[16 + o] = pf_sigmoid(acc[o]); rh[o] = pf_sigmoid(acc[8 + o]) * h0[o]; }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 32 + o];
+        rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_ZR, cv1, acc);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) rh[8 + o] = pf_sigmoid(acc[o]) * h0[8 + o];
+    }
+    // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b; the columns arrive as three chunks of
+    // [mu(8j .. 8j+7) | var(8j .. 8j+7)] (pfgru.py: pack_weights), each finishing eight units of h1
     float h1[PF_H];
+    auto cv2 = [&](int k) -> float { return (k < PF_H) ? rh[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
+    auto candidate = [&](auto jc, const float (&acc)[16]) {
+        constexpr int J = decltype(jc)::value;
 #pragma unroll
-    for (int u = 0; u < PF_H; ++u) {
-        float eps;
-        if constexpr (REC) {
-            eps = a_.eps_in[(slot * PF_P + q) * PF_H + u];
-        } else {
-            const uint64_t hx = pf_hash(pk + (uint64_t)u);
-            const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
-            const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
-            // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
-            // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
-            eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+        for (int w = 0; w < 8; ++w) {
+            const int u = 8 * J + w;
+            float eps;
+            if constexpr (REC) {
+                eps = a_.eps_in[(slot * PF_P + q) * PF_H + u];
+            } else {
+                const uint64_t hx = pf_hash(pk + (uint64_t)u);
+                const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
+                const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
+                // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
+                // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
+                eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+            }
+            const float var = acc[8 + w];
+            const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
+            const float y = acc[w] + eps * sp;
+            const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
+            h1[u] = (1.0f - z[u]) * nv + z[u] * h0[u];
         }
-        const float var = m[24 + u];
-        const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
-        const float y = m[u] + eps * sp;
-        const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
-        h1[u] = (1.0f - g[u]) * nv + g[u] * h0[u];
+    };
+    {
+        float acc[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + o];
+        rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_N, cv2, acc);
+        candidate(std::integral_constant<int, 0>{}, acc);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 16 + o];
+        rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_N, cv2, acc);
+        candidate(std::integral_constant<int, 1>{}, acc);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 32 + o];
+        rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_N, cv2, acc);
+        candidate(std::integral_constant<int, 2>{}, acc);
     }
     // ---- observation likelihood, log-softmax over the set's particles
     float lg = W[PF_OB];

@@ -71,15 +71,19 @@ _PF_ZR, _PF_ZRB, _PF_N, _PF_NB, _PF_O, _PF_OB, _PF_H0, _PF_H0B, _PF_H2, _PF_H2B,
 
 
 def pack_weights(cells) -> torch.Tensor:
-    """[A, PF_WEIGHT_FLOATS] float32: zr_t [28][48] | zr_b | n_t [28][48] | n_b | o_w [27] | o_b | h0_t [24][24] | h0_b | h2_w [2][24] | h2_b."""
+    """[A, PF_WEIGHT_FLOATS] float32: zr_t [28][48] | zr_b | n_t [28][48] (columns permuted, see below) | n_b | o_w [27] | o_b | h0_t [24][24] | h0_b | h2_w [2][24] | h2_b."""
     rows = []
     for c in cells:
         assert c.h_dim == 24 and c.num_particles == 40 and c.input_size == 3, "rs_pfgru_step is built for 40 particles x 24 units"
         w = torch.zeros(PF_WEIGHT_FLOATS, dtype=torch.float32, device=c.fc_z.weight.device)
         w[_PF_ZR:_PF_ZR + _PF_K * 48] = torch.cat([c.fc_z.weight, c.fc_r.weight], 0).t().reshape(-1)
         w[_PF_ZRB:_PF_N] = torch.cat([c.fc_z.bias, c.fc_r.bias], 0)
-        w[_PF_N:_PF_N + _PF_K * 48] = c.fc_n.weight.t().reshape(-1)
-        w[_PF_NB:_PF_O] = c.fc_n.bias
+        # fc_n's 48 outputs (mu | var) in the order the kernel consumes them: three 16-column chunks of [mu(8j .. 8j+7) | var(8j .. 8j+7)],
+        # so that a chunk completes eight units and its accumulators are the only part of the product that is live
+        perm = torch.tensor([(8 * (cc // 16) + cc % 16) if cc % 16 < 8 else (24 + 8 * (cc // 16) + cc % 16 - 8) for cc in range(48)],
+                            device=c.fc_n.weight.device)
+        w[_PF_N:_PF_N + _PF_K * 48] = c.fc_n.weight[perm].t().reshape(-1)
+        w[_PF_NB:_PF_O] = c.fc_n.bias[perm]
         w[_PF_O:_PF_OB] = c.fc_obs.weight.reshape(-1)
         w[_PF_OB] = c.fc_obs.bias[0]
         w[_PF_H0:_PF_H0B] = c.hid_obs[0].weight.t().reshape(-1)
