@@ -163,17 +163,32 @@ constexpr int LDS_FLOATS = TILE_F + 2 * P /* forward: cdf (f64); backward: taker
 template <int TI, int TJ>
 __device__ __forceinline__ void outer_acc(const float* DT, const float* IT, f4 (&acc)[TI][TJ], int lane) {
     const int c = lane & 15, q = lane >> 4;
+    // the fragments of k-step s + 1 are read from LDS while the MFMAs of step s run: at one wave per SIMD every read that is waited for
+    // right behind its issue costs an LDS round trip (~60 cycles, 55 k-steps per episode-step)
+    float an[TI], bn[TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) an[ti] = DT[(16 * ti + c) * SP + q];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) bn[tj] = IT[(16 * tj + c) * SP + q];
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
         float a[TI], b[TJ];
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) a[ti] = DT[(16 * ti + c) * SP + 4 * s + q];
+        for (int ti = 0; ti < TI; ++ti) a[ti] = an[ti];
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) b[tj] = IT[(16 * tj + c) * SP + 4 * s + q];
+        for (int tj = 0; tj < TJ; ++tj) b[tj] = bn[tj];
+        if (s + 1 < 11) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) an[ti] = DT[(16 * ti + c) * SP + 4 * (s + 1) + q];
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj) bn[tj] = IT[(16 * tj + c) * SP + 4 * (s + 1) + q];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, TI + TJ, 0);      // the next step's DS reads go out first ...
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TI * TJ, 0);      // ... then this step's MFMAs
     }
 }
 
