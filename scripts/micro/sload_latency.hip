@@ -84,6 +84,34 @@ __global__ void __launch_bounds__(64) overlap(const uint32_t* tab, int iters, un
     if (s == 1.2345f || acc == 12345u) sink[0] = s;
 }
 
+// a lone wave: 32 multiply-adds as 32 v_fmac_f32 or as 16 v_pk_fma_f32 (SGPR-pair weights as in the weight streams)
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <bool PK>
+__global__ void __launch_bounds__(64) lone_fma(const float* w, int iters, unsigned long long* out, float* sink) {
+    f2v acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f2v){(float)threadIdx.x + j, 1.0f};
+    const f2v w0 = (f2v){w[0], w[1]}, w1 = (f2v){w[2], w[3]};            // uniform -> SGPR pairs
+    const float x0 = 0.5f + threadIdx.x * 1e-3f, x1 = 0.25f;
+    unsigned long long t0 = now();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f2v ww = r ? w1 : w0;
+                const float xx = r ? x1 : x0;
+                if (PK) acc[j] = __builtin_elementwise_fma(ww, (f2v){xx, xx}, acc[j]);
+                else { acc[j].x = __builtin_fmaf(ww.x, xx, acc[j].x); acc[j].y = __builtin_fmaf(ww.y, xx, acc[j].y); }
+            }
+        }
+    }
+    unsigned long long t1 = now();
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    float s = 0; for (int j = 0; j < 8; ++j) s += acc[j].x + acc[j].y;
+    if (s == 1.2345f) sink[0] = s;
+}
+
 int main() {
     const int n = 4096;
     uint32_t* tab; unsigned long long* out;
@@ -132,6 +160,15 @@ int main() {
         overlap<64, false><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[1], o3, 8, hipMemcpyDeviceToHost);
         overlap<64, true><<<1, 64>>>(tab, it, o3, fs); hipMemcpy(&r[2], o3, 8, hipMemcpyDeviceToHost);
         printf("one wave: 64 v_fmac %.1f ticks; loads, 64 v_fmac, wait %.1f ticks per round\n", (double)r[1] / it, (double)r[2] / it);
+    }
+    {
+        unsigned long long* o4; float* fs2; float* wd; hipMalloc(&o4, 64); hipMalloc(&fs2, 4); hipMalloc(&wd, 16);
+        float hw[4] = {1.0001f, 0.9999f, 1.00005f, 0.99995f}; hipMemcpy(wd, hw, 16, hipMemcpyHostToDevice);
+        unsigned long long r[2]; const int it = 4000;
+        lone_fma<false><<<1, 64>>>(wd, it, o4, fs2); hipMemcpy(&r[0], o4, 8, hipMemcpyDeviceToHost);
+        lone_fma<true><<<1, 64>>>(wd, it, o4, fs2); hipMemcpy(&r[1], o4, 8, hipMemcpyDeviceToHost);
+        printf("one wave, 32 multiply-adds per round: 32 v_fmac_f32 %.1f ticks; 16 v_pk_fma_f32 (SGPR pair x splat) %.1f ticks\n",
+               (double)r[0] / it, (double)r[1] / it);
     }
     // s_memtime runs at a fixed 100 MHz on this part: print the ratio to the shader clock measured with a VALU loop elsewhere
     return 0;
