@@ -505,3 +505,66 @@ def test_non_default_layer_sizes_train_on_the_gpu():
     r = col.update()[0]
     after = torch.cat([p.detach().reshape(-1) for p in agents[0].agent.parameters()])
     assert np.isfinite([r.loss_policy, r.loss_critic, r.loss_predictor, r.kl_divergence, r.LocLoss]).all() and not torch.equal(before, after)
+
+
+def test_pfgru_pass_equals_per_step_launches():
+    """rs_pfgru_pass (the reset and every step of a no-grad K11 pass from one library call, the launches covering the prefix of episodes still
+    running) against rs_pfgru_reset + one rs_pfgru_step call per time step over ALL episodes: bit-identical predictions on every valid
+    (step, episode), for ragged episode lengths sorted in descending order."""
+    import ctypes as C
+    from radiation_ppo_amd import _lib
+    from radiation_ppo_amd.pfgru import pack_weights
+    from radiation_ppo_amd.rada2c import RNNAgentPPO
+    lib = _lib.load()
+    ag = RNNAgentPPO(id=0, seed=4)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    L, E = 17, 203                                                      # not a multiple of the six sets of a workgroup
+    lens = torch.sort(torch.randint(1, L + 1, (E,), generator=torch.Generator().manual_seed(2)), descending=True).values
+    lens[0] = L
+    X = torch.rand(L, E, 11, device="cuda", generator=g).contiguous()
+    keys = torch.randint(1, 1 << 40, (E,), device="cuda", generator=g, dtype=torch.int64)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wts = pack_weights([ag.agent.model])
+    episode = torch.ones(E, dtype=torch.int64, device="cuda")
+    calls = torch.arange(L, dtype=torch.int64, device="cuda").view(L, 1).expand(L, E).contiguous()
+    alpha = float(ag.agent.model.resamp_alpha)
+
+    def buffers():
+        return (torch.empty(1, E, 40, 24, device="cuda"), torch.empty(1, E, 40, device="cuda"), torch.zeros(L, E, 2, device="cuda"))
+    h, p, loc = buffers()
+    alive = [int((lens > t).sum()) for t in range(L)]
+    _lib.check(lib.rs_pfgru_pass(wts.data_ptr(), X.data_ptr(), h.data_ptr(), p.data_ptr(), keys.data_ptr(), episode.data_ptr(), calls.data_ptr(), alpha,
+                                 loc.data_ptr(), (C.c_int32 * L)(*alive), L, E, st), "rs_pfgru_pass")
+    h2, p2, loc2 = buffers()
+    _lib.check(lib.rs_pfgru_reset(h2.data_ptr(), p2.data_ptr(), keys.data_ptr(), episode.data_ptr(), calls[0].data_ptr(), None, E, 1, st), "reset")
+    for t in range(L):
+        _lib.check(lib.rs_pfgru_step(wts.data_ptr(), X[t].data_ptr(), h2.data_ptr(), p2.data_ptr(), keys.data_ptr(), episode.data_ptr(),
+                                     calls[t].data_ptr(), None, 1, alpha, loc2[t].data_ptr(), E, 1, st), "step")
+    valid = (torch.arange(L).view(L, 1) < lens.view(1, E)).cuda()
+    assert torch.equal(loc[valid], loc2[valid])
+    assert bool((loc[~valid] == 0).all())                               # launches stop at the episodes still running
+    assert lib.rs_pfgru_pass(wts.data_ptr(), X.data_ptr(), h.data_ptr(), p.data_ptr(), keys.data_ptr(), episode.data_ptr(), calls.data_ptr(), alpha,
+                             loc.data_ptr(), (C.c_int32 * L)(*alive[::-1]), L, E, st) == 1                    # RS_ERR_INVALID_ARG: not a prefix order
+
+
+def test_update_scratch_is_reused_across_epochs():
+    """rada2c.Scratch: the epoch-sized buffers of the K13 passes are views of persistent blocks with headroom -- a slightly larger request
+    does not allocate, a much larger one replaces the block; views of different names never alias."""
+    from radiation_ppo_amd.rada2c import Scratch
+    sc = Scratch()
+    a = sc.get("x", (10, 1000), torch.float32, "cuda")
+    ptr = a.data_ptr()
+    b = sc.get("x", (10, 1100), torch.float32, "cuda")                  # within the 1/8 headroom
+    assert b.data_ptr() == ptr and b.shape == (10, 1100)
+    c = sc.get("y", (10, 1000), torch.float32, "cuda")
+    assert c.data_ptr() != ptr
+    d = sc.get("x", (10, 4000), torch.float32, "cuda")
+    assert d.numel() == 40000 and sc.bufs[("x", torch.float32, "cuda")].numel() >= 45000
+
+
+def test_host_read_returns_the_device_values():
+    from radiation_ppo_amd.ppo import host_read
+    t = torch.arange(7, dtype=torch.float64, device="cuda") * 0.5
+    assert host_read(t) == [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0]
+    assert host_read(t * 2) == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]      # the pinned staging buffer is reused
+    assert host_read(torch.tensor([1.0, 2.0])) == [1.0, 2.0]            # CPU tensors: plain tolist
