@@ -72,7 +72,7 @@ def _grads(module, out, wgt):
     return [p.grad.detach().clone() for p in module.parameters()]
 
 
-@pytest.mark.parametrize("S", [1, 193, 2600])         # one image, fewer than the grid, several images per workgroup
+@pytest.mark.parametrize("S", [1, 2, 5, 193, 2600])   # one image, a partly filled round of three, fewer than the grid, several rounds per workgroup
 def test_trunk_forward_and_backward_match_torch(S):
     """Reference = the same nn.Sequential modules evaluated by PyTorch in float64 on the CPU (dense stacks)."""
     import copy
@@ -92,7 +92,7 @@ def test_trunk_forward_and_backward_match_torch(S):
         got = actor.logits_from_maps(maps, cells, pcells, a)
         _close(got, ref.detach(), f"actor logits a={a}")
         keep = ~_fragile(actor64.actor, dense64)
-        assert keep.float().mean() > 0.5
+        assert keep.float().mean() >= 0.5                  # (images with a pool / ReLU near-tie carry no gradient weight in this test)
         wgt = torch.randn_like(got) * keep.cuda().unsqueeze(1)
         gref = _grads(actor64, ref, wgt.double().cpu())
         ggot = _grads(actor, got, wgt)
