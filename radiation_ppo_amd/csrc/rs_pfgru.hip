@@ -340,7 +340,9 @@ __global__ void __launch_bounds__(256) rs_pfgru_draws_kernel(const int64_t* __re
             const uint64_t hx = pf_hash(k1 + (uint64_t)(q + j));
             const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);
             const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
-            v[j] = sqrtf(-2.0f * logf(u1)) * cosf(6.2831855f * u2);              // pfgru.py: hash_normal (library functions, as torch)
+            // pfgru.py: hash_normal on the hardware transcendentals, as the step kernel evaluates it (v_log_f32 is log2, v_cos_f32 takes
+            // revolutions; 1 ulp each): the library logf / cosf made this kernel instruction bound at a quarter of the HBM fill rate
+            v[j] = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
         }
         *reinterpret_cast<float4*>(ew + q) = make_float4(v[0], v[1], v[2], v[3]);
     }
