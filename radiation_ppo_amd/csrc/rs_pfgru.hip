@@ -170,20 +170,28 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
     auto cv2 = [&](int k) -> float { return (k < PF_H) ? rh[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
     auto candidate = [&](auto jc, const float (&acc)[16]) {
         constexpr int J = decltype(jc)::value;
+        float eps8[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < 8; w += 2) {
             const int u = 8 * J + w;
-            float eps;
             if constexpr (REC) {
-                eps = a_.eps_in[(slot * PF_P + q) * PF_H + u];
+                eps8[w] = a_.eps_in[(slot * PF_P + q) * PF_H + u];
+                eps8[w + 1] = a_.eps_in[(slot * PF_P + q) * PF_H + u + 1];
             } else {
+                // pfgru.py: hash_normal -- one hash per PAIR of units, Box-Muller's cosine for the even unit and sine for the odd one, on
+                // the hardware transcendentals (1 ulp each; v_cos_f32 / v_sin_f32 take revolutions: no range reduction): |error| ~ 1e-6
                 const uint64_t hx = pf_hash(pk + (uint64_t)u);
                 const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
                 const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
-                // Box-Muller on the hardware transcendentals (1 ulp each; v_cos_f32 takes revolutions: cos(2 pi u2) is ONE instruction,
-                // the library cosf would drag its Payne-Hanek reduction along): |error| ~ 1e-6 on eps, inside the test tolerance
-                eps = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+                const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));
+                eps8[w] = r * __builtin_amdgcn_cosf(u2);
+                eps8[w + 1] = r * __builtin_amdgcn_sinf(u2);
             }
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int u = 8 * J + w;
+            const float eps = eps8[w];
             const float var = acc[8 + w];
             const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
             const float y = acc[w] + eps * sp;
@@ -336,13 +344,16 @@ __global__ void __launch_bounds__(256) rs_pfgru_draws_kernel(const int64_t* __re
     for (int q = 0; q < PF_H; q += 4) {
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; j += 2) {
+            // pfgru.py: hash_normal -- one hash per pair of units (cosine / sine of Box-Muller), on the hardware transcendentals as the
+            // step kernel evaluates it (v_log_f32 is log2, v_cos_f32 / v_sin_f32 take revolutions; 1 ulp each): with the library logf /
+            // cosf this kernel was instruction bound at a quarter of the HBM fill rate
             const uint64_t hx = pf_hash(k1 + (uint64_t)(q + j));
             const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);
             const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
-            // pfgru.py: hash_normal on the hardware transcendentals, as the step kernel evaluates it (v_log_f32 is log2, v_cos_f32 takes
-            // revolutions; 1 ulp each): the library logf / cosf made this kernel instruction bound at a quarter of the HBM fill rate
-            v[j] = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+            const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));
+            v[j] = r * __builtin_amdgcn_cosf(u2);
+            v[j + 1] = r * __builtin_amdgcn_sinf(u2);
         }
         *reinterpret_cast<float4*>(ew + q) = make_float4(v[0], v[1], v[2], v[3]);
     }

@@ -56,12 +56,18 @@ def hash_uniform(key: torch.Tensor) -> torch.Tensor:
 
 
 def hash_normal(key: torch.Tensor) -> torch.Tensor:
-    """int64 keys -> float32 standard normals: Box-Muller in float32 on two 24-bit uniforms cut from ONE hash
-    (bits 63..40 -> u1 in (0, 1], bits 39..16 -> u2 in [0, 1)); what the step kernel evaluates per (particle, unit)."""
-    x = hash_bits(key)
+    """int64 keys -> float32 standard normals by Box-Muller in float32.  The LAST dimension of `key` enumerates consecutive units
+    (key[..., u] = base + u, an even count): ONE hash per PAIR of units -- the even unit's key gives two 24-bit uniforms
+    (bits 63..40 -> u1 in (0, 1], bits 39..16 -> u2 in [0, 1)), the even unit takes r cos(2 pi u2), the odd one r sin(2 pi u2).
+    What the step kernel (K11) and rs_pfgru_draws evaluate per (particle, unit pair): half the hashes, logs and roots of one hash per
+    unit."""
+    assert key.shape[-1] % 2 == 0
+    x = hash_bits(key[..., 0::2])
     u1 = (_lsr(x, 40) + 1).float() * (1.0 / 16777216.0)
     u2 = (_lsr(x, 16) & 0xFFFFFF).float() * (1.0 / 16777216.0)
-    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(6.2831855 * u2)
+    r = torch.sqrt(-2.0 * torch.log(u1))
+    ang = 6.2831855 * u2
+    return torch.stack((r * torch.cos(ang), r * torch.sin(ang)), dim=-1).reshape(key.shape)
 
 
 # packed per-owner weights of csrc/rs_pfgru.hip (floats): offsets of the blocks and the owner stride
