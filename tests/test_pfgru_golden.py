@@ -155,3 +155,16 @@ def test_bank_batched_over_owners_equals_the_cell():
     bank.load_state_dict(1, sd)
     bank.reset()
     assert not torch.allclose(bank.predict(obs)[:, 1], got[:, 1])
+
+
+def test_hash_normal_pairs_are_standard_and_uncorrelated():
+    """hash_normal draws one hash per PAIR of units (Box-Muller's cosine and sine): both members are N(0, 1) and uncorrelated."""
+    keys = (torch.arange(20000, dtype=torch.int64).view(-1, 1) * 1048583 + 17) * 4096 + torch.arange(24, dtype=torch.int64).view(1, -1)
+    z = hash_normal(keys).double()
+    assert z.shape == (20000, 24)
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.var()) - 1.0) < 1e-2
+    even, odd = z[:, 0::2].reshape(-1), z[:, 1::2].reshape(-1)
+    assert abs(float((even * odd).mean())) < 5e-3                                   # cos / sin of one angle: uncorrelated
+    assert abs(float((even ** 2 * odd ** 2).mean()) - 1.0) < 2e-2                   # ... and independent in the second moments
+    assert abs(float((z ** 4).mean()) - 3.0) < 5e-2                                 # kurtosis of a normal
+    assert float(z.abs().max()) < 6.0                                               # 24-bit u1: |z| <= sqrt(2 ln 2^24) = 5.77
