@@ -98,8 +98,8 @@ __device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const fl
 #pragma unroll
         for (int j = 0; j < 4; ++j) { z[u + j] = sigmoidf_(g[u + j]); r4[j] = sigmoidf_(g[H + u + j]); rh[u + j] = r4[j] * h0[u + j]; }
         if (store) {
-            gw[u / 4] = make_float4(z[u], z[u + 1], z[u + 2], z[u + 3]);
-            gw[6 + u / 4] = make_float4(r4[0], r4[1], r4[2], r4[3]);
+            gw[(u / 4) * P] = make_float4(z[u], z[u + 1], z[u + 2], z[u + 3]);
+            gw[(6 + u / 4) * P] = make_float4(r4[0], r4[1], r4[2], r4[3]);
         }
     }
     float m[48];
@@ -123,8 +123,8 @@ __device__ __forceinline__ void pf_cell(cmem_t W, const float (&h0)[H], const fl
             lg = fmaf(W[T_O + u + j], h1[u + j], lg);
         }
         if (store) {
-            gw[12 + u / 4] = make_float4(n4[0], n4[1], n4[2], n4[3]);
-            gw[18 + u / 4] = make_float4(es4[0], es4[1], es4[2], es4[3]);
+            gw[(12 + u / 4) * P] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+            gw[(18 + u / 4) * P] = make_float4(es4[0], es4[1], es4[2], es4[3]);
         }
     }
 #pragma unroll
@@ -143,7 +143,9 @@ struct TrArgs {
     const double* u;          // [L][E][P]  resampling uniforms; NULL: idx[] holds the indices to take (recorded draws)
     float* hs;                // [L][E][P][H] scratch: resampled particles after every step
     float* ps;                // [L][E][P]    scratch: their log weights
-    float* gates;             // [L][E][P][4 H] scratch: z | r | n | eps * softplus'(var) of the forward walk (the backward walk reloads them)
+    float* gates;             // [L][E][4 H / 4][P] float4 scratch: z | r | n | eps * softplus'(var) of the forward walk, QUAD-major (quad j of all 40
+                              // particles contiguous: the forward's stores are 640 B runs and the backward's LDS reads are conflict free; with a
+                              // particle's 96 floats contiguous every lane of the backward read hit the same four banks)
     int32_t* idx;             // [L][E][P]    resampling indices (output; constants of the backward pass)
     float* loss;              // [E]
     float* grads;             // [E][RS_PFGRU_TRAIN_GRAD_FLOATS]
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(FW_NT, 2) rs_pfgru_train_fwd_kernel(TrArgs a_)
             for (int k = 0; k < IN; ++k) x[k] = o[k];
         }
         load24(a_.eps + te * PH + (size_t)q * H, eps);
-        pf_cell(W, h0, x, eps, reinterpret_cast<float4*>(a_.gates + (te * P + q) * (size_t)(4 * H)), on, h1, lg);
+        pf_cell(W, h0, x, eps, reinterpret_cast<float4*>(a_.gates + te * (size_t)(P * 4 * H)) + q, on, h1, lg);
         K13_STAMP(0)                                                 // forward: loads + cell
         lg += p0;
         if (act) va[q] = lg;
@@ -444,10 +446,10 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA of this step's gates (and the loads above) have landed
             __builtin_amdgcn_wave_barrier();
             {
-                const float4* gr = reinterpret_cast<const float4*>(pre + pl * (4 * H));
+                const float4* gr = reinterpret_cast<const float4*>(pre) + pl;        // quad j of particle pl: gr[j * P]
 #pragma unroll
                 for (int u = 0; u < H; u += 4) {
-                    const float4 a = gr[u / 4], b = gr[6 + u / 4], c = gr[12 + u / 4], d = gr[18 + u / 4];
+                    const float4 a = gr[(u / 4) * P], b = gr[(6 + u / 4) * P], c = gr[(12 + u / 4) * P], d = gr[(18 + u / 4) * P];
                     z[u] = a.x; z[u + 1] = a.y; z[u + 2] = a.z; z[u + 3] = a.w;
                     r[u] = b.x; r[u + 1] = b.y; r[u + 2] = b.z; r[u + 3] = b.w;
                     n[u] = c.x; n[u + 1] = c.y; n[u + 2] = c.z; n[u + 3] = c.w;
