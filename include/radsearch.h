@@ -358,7 +358,7 @@ int rs_pfgru_draws(const int64_t* keys, int32_t episodes, int32_t steps, float* 
  *   obs [L][E][11] (columns 0..2 used), target [L][E][2], bp [L][E], lens [E] (1..L; steps beyond are never touched), w_ep [E]
  *   h0 / eps / u  the draws of rs_pfgru_draws; u may be NULL: idx[] is then INPUT -- the resampling indices to take (the ones
  *                 torch.multinomial returned in a recorded run of the reference, tests/golden/rada2c_core.npz)
- *   hs [L][E][40][24], ps [L][E][40], gates [L][E][24][40][4]  scratch (the resampled particle sets; the forward walk's gates z | r | n |
+ *   hs [L][E][6][40][4], ps [L][E][40], gates [L][E][24][40][4]  scratch (the resampled particle sets; the forward walk's gates z | r | n |
  *                 eps * softplus'(var), reloaded by the backward walk), idx [L][E][40] the resampling indices taken (output when u is given)
  *   loss [E] = w_ep[e] * total_e;  grads [E][RS_PFGRU_TRAIN_GRAD_FLOATS] = the episode's gradient slab:
  *   d[fc_z | fc_r] [48][28] (column 27 = bias) | d fc_n [48][28] | d hid_obs[0] [24][25] | d hid_obs[2] [2][25] | d fc_obs [28];

@@ -141,7 +141,7 @@ struct TrArgs {
     const float* h0;          // [E][P][H]  initial particles
     const float* eps;         // [L][E][P][H]
     const double* u;          // [L][E][P]  resampling uniforms; NULL: idx[] holds the indices to take (recorded draws)
-    float* hs;                // [L][E][P][H] scratch: resampled particles after every step
+    float* hs;                // [L][E][H / 4][P] float4 scratch: resampled particles after every step, quad-major
     float* ps;                // [L][E][P]    scratch: their log weights
     float* gates;             // [L][E][4 H / 4][P] float4 scratch: z | r | n | eps * softplus'(var) of the forward walk, QUAD-major (quad j of all 40
                               // particles contiguous: the forward's stores are 640 B runs and the backward's LDS reads are conflict free; with a
@@ -338,9 +338,9 @@ __global__ void __launch_bounds__(FW_NT, 2) rs_pfgru_train_fwd_kernel(TrArgs a_)
         __syncthreads();                                             // 6
         p0 = pn - (logf(fw_sum40(va)) + mx2);
         if (on) {
-            float* hw = a_.hs + te * PH + (size_t)q * H;
+            float4* hw = reinterpret_cast<float4*>(a_.hs + te * PH) + q;          // quad-major, as the gates: quad j of all particles contiguous
 #pragma unroll
-            for (int u = 0; u < H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
+            for (int u = 0; u < H; u += 4) hw[(u / 4) * P] = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
             a_.ps[te * P + q] = p0;
             a_.idx[te * P + q] = idx;
         }
@@ -432,11 +432,19 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         // everything else the step reads from HBM is requested here, in one round trip
         const int idx = a_.idx[te * P + pl];
         float h1r[H];
-        load24(a_.hs + te * PH + (size_t)pl * H, h1r);
+        auto load24q = [&](const float* blk, float (&dst)[H]) {             // a particle set stored quad-major ([H / 4][P] float4)
+            const float4* src = reinterpret_cast<const float4*>(blk) + pl;
+#pragma unroll
+            for (int u = 0; u < H; u += 4) {
+                const float4 v4 = src[(u / 4) * P];
+                dst[u] = v4.x; dst[u + 1] = v4.y; dst[u + 2] = v4.z; dst[u + 3] = v4.w;
+            }
+        };
+        load24q(a_.hs + te * PH, h1r);
         const float ps_t = a_.ps[te * P + pl];
         {
             if (t > 0) {
-                load24(a_.hs + (te - E) * PH + (size_t)pl * H, h0);
+                load24q(a_.hs + (te - E) * PH, h0);
                 p0 = a_.ps[(te - E) * P + pl];
             } else {
                 load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
