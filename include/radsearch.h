@@ -313,7 +313,9 @@ int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t
  * for every (owner, env) at once: 40 particles x 24 hidden units.
  *   weights   [A][RS_PFGRU_WEIGHT_FLOATS]  per-owner packed parameters (layout: csrc/rs_pfgru.hip; packer: pfgru.py)
  *   obs       [N][A][11]   the owner's own row supplies (reading, x, y)
- *   h, p      [A][N][40][24] particles, [A][N][40] log weights; read; written back when carry_hidden != 0 (mask[n] != 0)
+ *   h, p      [A][N][6][40][4] particles, QUAD-major (a set's 40 particles x 24 units as six [40] x float4 slabs: unit u of particle q at
+ *             ((u / 4) * 40 + q) * 4 + u % 4 -- coalesced for one particle per lane), [A][N][40] log weights; read; written back when
+ *             carry_hidden != 0 (mask[n] != 0)
  *   base_key  [A][N], episode [N], calls [N]   counters of the draw hash (documented RNG deviation: the reference draws
  *             from torch's global generator)
  *   pred      [N][A][2]    location prediction (scaled coordinates, >= 0: the reference's MLP ends in a ReLU); with a mask only the
@@ -333,12 +335,14 @@ int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, co
                   const int64_t* calls, double alpha, float* pred, const int32_t* alive, int32_t steps, int32_t episodes, rs_stream_t stream);
 /* The same step with the draws supplied instead of hashed: eps [A][N][40][24] = the reparameterisation noise, idx [A][N][40] = the
  * resampling indices (what FloatTensor.normal_ / torch.multinomial returned in a recorded run of the reference, :1485-1530).  The
- * arithmetic is the product kernel's (one template, two instantiations); used to hold it to tests/golden/pfgru.npz directly. */
+ * arithmetic is the product kernel's (one template, two instantiations); used to hold it to tests/golden/pfgru.npz directly.  h is
+ * quad-major as in rs_pfgru_step; eps stays particle-major. */
 int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, float* p, const float* eps, const int32_t* idx,
                            const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
                            rs_stream_t stream);
 /* reset_hidden (RADTEAM_core.py:2030-2033, PFGRUCell.init_hidden :1643-1652) for the envs with mask[n] != 0 (all when null):
- * h0 ~ U[0,1) from the draw hash, p0 = log(1/40).  episode[] / calls[] must already count the new episode. */
+ * h0 ~ U[0,1) from the draw hash (written in rs_pfgru_step's quad-major layout), p0 = log(1/40).  episode[] / calls[] must already count
+ * the new episode. */
 int rs_pfgru_reset(float* h, float* p, const int64_t* base_key, const int64_t* episode, const int64_t* calls, const uint8_t* mask,
                    int32_t num_envs, int32_t num_agents, rs_stream_t stream);
 

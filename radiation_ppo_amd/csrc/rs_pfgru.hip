@@ -50,7 +50,7 @@ __device__ __forceinline__ float pf_sigmoid(float v) { return __builtin_amdgcn_r
 struct PfArgs {
     const float* w;           // [A][PF_STRIDE]
     const float* obs;         // [N][A][11]
-    float* h;                 // [A][N][P][H]
+    float* h;                 // [A][N][H / 4][P][4]: quad-major particle sets
     float* p;                 // [A][N][P]
     const int64_t* base;      // [A][N]  per (owner, env) key
     const int64_t* episode;   // [N]
@@ -118,11 +118,13 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
 
     cmem_t W = as_cmem(a_.w + (size_t)own * PF_STRIDE);
     const size_t slot = (size_t)own * a_.N + n;
-    const float* hp = a_.h + (slot * PF_P + q) * PF_H;
+    // the particle sets are stored QUAD-major ([H / 4][P] float4 per set): a load / store instruction of a set's 40 lanes is 640 contiguous
+    // bytes (a particle's 24 floats contiguous meant 16-byte pieces at a 96-byte stride; K13's scratch: 14 % of its forward walk)
+    const float4* hp = reinterpret_cast<const float4*>(a_.h + slot * PF_P * PF_H) + q;
     float h0[PF_H];
 #pragma unroll
     for (int u = 0; u < PF_H; u += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(hp + u);
+        const float4 v = hp[(u / 4) * PF_P];
         h0[u] = v.x; h0[u + 1] = v.y; h0[u + 2] = v.z; h0[u + 3] = v.w;
     }
     const float p0 = a_.p[slot * PF_P + q];
@@ -271,9 +273,9 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
     __syncthreads();                                                // 6
     p1 = pn - (logf(pk_sum40(va)) + mx2);
     if (a_.carry && live) {
-        float* hw = a_.h + (slot * PF_P + q) * PF_H;
+        float4* hw = reinterpret_cast<float4*>(a_.h + slot * PF_P * PF_H) + q;
 #pragma unroll
-        for (int u = 0; u < PF_H; u += 4) *reinterpret_cast<float4*>(hw + u) = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
+        for (int u = 0; u < PF_H; u += 4) hw[(u / 4) * PF_P] = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
         a_.p[slot * PF_P + q] = p1;
     }
     // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
@@ -315,13 +317,13 @@ __global__ void __launch_bounds__(256) rs_pfgru_reset_kernel(float* h, float* p,
     const uint64_t kb = (uint64_t)base[slot] * 1000003ull;
     const uint64_t ctr8 = ((uint64_t)episode[n] * 100003ull + (uint64_t)calls[n]) * 8ull;
     const uint64_t pk = (kb ^ (ctr8 * 0xA24BAED4963EE407ull)) * 1048583ull + (uint64_t)pl * 4096ull;
-    float* hw = h + i * PF_H;
+    float4* hw = reinterpret_cast<float4*>(h + slot * PF_P * PF_H) + pl;           // quad-major, as the step kernel reads it
 #pragma unroll
     for (int u = 0; u < PF_H; u += 4) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = (float)((double)(pf_hash(pk + (uint64_t)(u + q)) >> 11) * (1.0 / 9007199254740992.0));
-        *reinterpret_cast<float4*>(hw + u) = make_float4(v[0], v[1], v[2], v[3]);
+        hw[(u / 4) * PF_P] = make_float4(v[0], v[1], v[2], v[3]);
     }
     p[i] = -3.6888794541139363f;                                   // float32(log(1 / 40))
 }

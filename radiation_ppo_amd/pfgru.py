@@ -211,11 +211,37 @@ class PredictorBank:
         self._base = hash_uniform((env.view(1, -1) * 64 + own.view(-1, 1)) ^ _s64(int(seed) * 0x2545F4914F6CDD1D)).mul(2.0 ** 52).long()   # [A, N]
         self._pu = (torch.arange(P, dtype=torch.int64, device=self.dev).view(P, 1) * 4096
                     + torch.arange(H, dtype=torch.int64, device=self.dev).view(1, H))                                                          # [P, H]
-        self.h = torch.zeros(number_agents, num_envs, P, H, dtype=torch.float32, device=self.dev)
+        # the kernels keep the particle sets quad-major ([A, N, H / 4, P, 4], include/radsearch.h); `h` is the logical [A, N, P, H] view of it
+        self._hq = torch.zeros(number_agents, num_envs, H // 4, P, 4, dtype=torch.float32, device=self.dev) if impl == "hip" else None
+        self._h = None if impl == "hip" else torch.zeros(number_agents, num_envs, P, H, dtype=torch.float32, device=self.dev)
         self.p = torch.full((number_agents, num_envs, P), math.log(1.0 / P), dtype=torch.float32, device=self.dev)
         # draw counters per env: episodes begun, predictions made in the current episode
         self.episode = torch.zeros(num_envs, dtype=torch.int64, device=self.dev)
         self.calls = torch.zeros(num_envs, dtype=torch.int64, device=self.dev)
+
+    @staticmethod
+    def to_quads(h: torch.Tensor) -> torch.Tensor:
+        """[..., P, H] particle sets -> the kernels' quad-major [..., H / 4, P, 4] (contiguous)."""
+        *lead, P, H = h.shape
+        return h.reshape(*lead, P, H // 4, 4).transpose(-3, -2).contiguous()
+
+    @staticmethod
+    def from_quads(hq: torch.Tensor) -> torch.Tensor:
+        """the kernels' quad-major [..., H / 4, P, 4] -> [..., P, H]."""
+        *lead, Q, P, four = hq.shape
+        return hq.transpose(-3, -2).reshape(*lead, P, Q * four)
+
+    @property
+    def h(self) -> torch.Tensor:
+        """[A, N, P, H] particle sets (impl "hip": a copy out of the quad-major device storage)."""
+        return self._h if self._hq is None else self.from_quads(self._hq)
+
+    @h.setter
+    def h(self, value: torch.Tensor) -> None:
+        if self._hq is None:
+            self._h = value
+        else:
+            self._hq.copy_(self.to_quads(value))
 
     def parameters(self, a: int):
         return self.cells[a].parameters()
@@ -233,7 +259,7 @@ class PredictorBank:
         if self.impl == "hip":
             m8 = None if mask is None else m1.to(torch.uint8)
             with _lib.timed("rs_pfgru_reset"):
-                _lib.check(self._lib.rs_pfgru_reset(self.h.data_ptr(), self.p.data_ptr(), self._base.data_ptr(), self.episode.data_ptr(),
+                _lib.check(self._lib.rs_pfgru_reset(self._hq.data_ptr(), self.p.data_ptr(), self._base.data_ptr(), self.episode.data_ptr(),
                                                     self.calls.data_ptr(), None if m8 is None else m8.data_ptr(), self.N, self.A,
                                                     self._stream()), "rs_pfgru_reset")
             return
@@ -284,7 +310,7 @@ class PredictorBank:
             assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (N, A, _lib.RS_OBS_DIM)
             m8 = None if mask is None else mask.to(torch.uint8)
             with _lib.timed("rs_pfgru_step"):
-                _lib.check(self._lib.rs_pfgru_step(self._packed().data_ptr(), obs.data_ptr(), self.h.data_ptr(), self.p.data_ptr(),
+                _lib.check(self._lib.rs_pfgru_step(self._packed().data_ptr(), obs.data_ptr(), self._hq.data_ptr(), self.p.data_ptr(),
                                                    self._base.data_ptr(), self.episode.data_ptr(), self.calls.data_ptr(),
                                                    None if m8 is None else m8.data_ptr(), 1 if self.carry_hidden else 0,
                                                    float(self.cells[0].resamp_alpha), self._pred.data_ptr(), N, A, self._stream()),
@@ -335,7 +361,7 @@ class PredictorBank:
 
     def load_resume_state(self, st) -> None:
         if self.impl == "hip":                                     # in place: a captured collector step refers to these tensors
-            self.h.copy_(st["h"]); self.p.copy_(st["p"])
+            self.h = st["h"]; self.p.copy_(st["p"])
         else:
             self.h, self.p = st["h"].clone(), st["p"].clone()
         self.episode.copy_(st["episode"]); self.calls.copy_(st["calls"])

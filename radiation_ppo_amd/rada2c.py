@@ -612,7 +612,8 @@ class RNNAgentPPO:
         L, E = X.shape[0], X.shape[1]
         dev = X.device
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        h = draws.pf_h0().clone().view(1, E, 40, 24)
+        from .pfgru import PredictorBank
+        h = PredictorBank.to_quads(draws.pf_h0().view(1, E, 40, 24))          # the kernel's quad-major particle sets
         p = torch.full((1, E, 40), math.log(1.0 / 40), dtype=torch.float32, device=dev)
         wts = pack_weights([self.agent.model])
         loc = torch.zeros(L, E, 2, dtype=torch.float32, device=dev)

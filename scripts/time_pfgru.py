@@ -33,7 +33,7 @@ idx = torch.randint(0, 40, (A, N, 40), device="cuda", dtype=torch.int32)
 pred = torch.empty(N, A, 2, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def rec():
-    _lib.check(lib.rs_pfgru_step_recorded(b._packed().data_ptr(), obs.data_ptr(), b.h.data_ptr(), b.p.data_ptr(), eps.data_ptr(), idx.data_ptr(),
+    _lib.check(lib.rs_pfgru_step_recorded(b._packed().data_ptr(), obs.data_ptr(), b._hq.data_ptr(), b.p.data_ptr(), eps.data_ptr(), idx.data_ptr(),
                                           None, 1, 0.7, pred.data_ptr(), N, A, st), "rec")
 for _ in range(10):
     rec()

@@ -415,7 +415,7 @@ def test_gru_h0_reset_kernel_equals_the_hash_composition():
         got = col.h.clone()
         # rewind and take the composition
         col.episodes_begun.copy_(begun); col.h.copy_(h_before)
-        col.bank.h.copy_(pf[0]); col.bank.p.copy_(pf[1]); col.bank.episode.copy_(pf[2]); col.bank.calls.copy_(pf[3])
+        col.bank.h = pf[0]; col.bank.p.copy_(pf[1]); col.bank.episode.copy_(pf[2]); col.bank.calls.copy_(pf[3])
         col.use_k14 = False
         col._reset_hidden(mask)
         col.use_k14 = True
