@@ -215,6 +215,9 @@ __device__ __forceinline__ void outer_store(const f4 (&acc)[TI][TJ], float* out,
 // the fused kernel did.  Lane-packed like K11 (csrc/rs_pfgru.hip): six episodes of 40 particles per 256-thread workgroup, what couples
 // an episode's particles goes through LDS and workgroup barriers, every lane reducing its episode's 40 values in index order.
 constexpr int FW_SETS = 6, FW_NT = 256;
+#ifndef K13_FW_OCC
+#define K13_FW_OCC 2          // waves per SIMD the register budget is cut for.  A/B at 16 384 episodes: 2 (179 VGPRs) 51.6 ms per pass, 3 (168 + 52 B scratch) 51.9, 4 (128 + 220 B) 55.2
+#endif
 constexpr int FW_TILE = 0, FW_CDF = P * ROW, FW_VA = FW_CDF + 2 * P, FW_VB = FW_VA + P, FW_VC = FW_VB + P, FW_STRIDE = 1228;
 static_assert(FW_VC + P <= FW_STRIDE && FW_STRIDE % 4 == 0 && FW_STRIDE % 32 == 12 && FW_CDF % 2 == 0, "LDS layout of an episode's particle set");
 
@@ -237,7 +240,7 @@ __device__ __forceinline__ float fw_sum40(const float* v) {          // index or
     return s;
 }
 
-__global__ void __launch_bounds__(FW_NT, 2) rs_pfgru_train_fwd_kernel(TrArgs a_) {
+__global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(TrArgs a_) {
     __shared__ __align__(16) float smem[FW_SETS * FW_STRIDE];
     __shared__ int lens_s[FW_SETS];
     const int tid = threadIdx.x;
