@@ -208,6 +208,69 @@ __device__ __forceinline__ void outer_store(const f4 (&acc)[TI][TJ], float* out,
             }
 }
 
+// Transposed products of the backward walk on the matrix cores: out[u] (u < 24, for the lane's particle) = sum over o < 4 KK of
+// Wt[u][o] d[o][particle], with d already staged in DT for the weight gradient's outer product (DT [o][SP], column = particle) and the
+// weights k-major in the packed set (Wt[u][o] = wt[u * WS + o]).  D [u][particle] = A [u][o] B [o][particle]: A fragments are per-lane
+// global loads of the weights (L1 / L2 hits; requested by mvt_fetch BEFORE the outer product that precedes the product, so their latency
+// is covered), B fragments are LDS reads of DT, and the 4 consecutive units a lane receives for one particle go through `tile` back to
+// the particle's own lane.  As 1 152 scalar-streamed FMAs at the lone-wave issue rate one product took ~5 700 cycles; 72 MFMAs take ~2 300.
+// Rows u >= 24 (clamped to row 23) and columns >= 44 (whatever follows DT) are computed and dropped: an element of D depends on its own
+// row of A and column of B only.
+template <int KK, int WS>
+__device__ __forceinline__ void mvt_fetch(const float* wt, float (&wa)[2][KK], int lane) {
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+    const int c = lane & 15, q = lane >> 4;
+    gptr_t r0 = (gptr_t)wt + c * WS + q;
+    gptr_t r1 = (gptr_t)wt + (c < 8 ? 16 + c : H - 1) * WS + q;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) { wa[0][kk] = r0[4 * kk]; wa[1][kk] = r1[4 * kk]; }
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * KK, 0);          // all requests go out HERE: left alone, the scheduler sinks each
+}                                                                    // load to its MFMA and waits for it there (24 exposed round trips)
+
+template <int KK, bool ACC>
+__device__ __forceinline__ void mvt_mfma(const float (&wa)[2][KK], const float* DT, float* tile, int lane, float (&out)[H]) {
+    const int c = lane & 15, q = lane >> 4;
+    f4 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f4{0, 0, 0, 0};
+    float bn[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) bn[nt] = DT[q * SP + 16 * nt + c];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        float b[3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[nt] = bn[nt];
+        if (kk + 1 < KK) {
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) bn[nt] = DT[(4 * (kk + 1) + q) * SP + 16 * nt + c];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][kk], b[nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int pp = 16 * nt + c, u0 = 16 * mt + 4 * q;
+            if (u0 < H && pp < 44) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tile[pp * ROW + u0 + v] = acc[mt][nt][v];
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    const float* row = tile + (lane < 44 ? lane : 43) * ROW;
+#pragma unroll
+    for (int u = 0; u < H; ++u) out[u] = ACC ? out[u] + row[u] : row[u];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // The forward walk of a training pass as its own launch (round 3).  Inside the 512-register backward kernel it ran at one wave per SIMD,
 // where a lone wave issues a VALU instruction only every ~5 cycles (scripts/micro/sload_latency.hip: 32 v_fmac = 180 cycles; two or
 // more waves share the SIMD at 2.5): the walk needs no gradient accumulators, fits 2 waves per SIMD without spilling (175 VGPRs; at 3 waves 9
@@ -373,6 +436,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     // invariant and the forward and transposed products read the same rows -- LICM / GVN would otherwise hoist or keep thousands of
     // scalar loads and spill them to VGPR lanes (measured: 3 920 SGPR spills, 24 k v_readlane)
     auto wptr = [&]() -> cmem_t { const float* w = a_.w; asm volatile("" : "+s"(w)); return as_cmem(w); };
+    auto wglob = [&]() -> const float* { const float* w = a_.w; asm volatile("" : "+s"(w)); return w; };      // the same, for per-lane (vector) loads
     const int E = a_.E;
     const int len = (int)a_.lens[e];
     const float al = a_.alpha, floor_ = a_.floor_;
@@ -547,18 +611,17 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float du[H];
 #pragma unroll
         for (int k = 0; k < H; ++k) du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
-        float dv[H];
-#pragma unroll
-        for (int o = 0; o < H; ++o) dv[o] = 0.0f;
-        mvt<H, 32, H>(wptr() + T_H0, [&](int o) -> float { return du[o < H ? o : 0]; }, dv);
         if (stage) {
 #pragma unroll
             for (int k = 0; k < H; ++k) { DT[k * SP + lane] = act41 ? du[k] : 0.0f; IT[k * SP + lane] = act41 ? v[k] : 0.0f; }
             IT[H * SP + lane] = act41 ? 1.0f : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
+        float wh[2][6];
+        mvt_fetch<6, 32>(wglob() + T_H0, wh, lane);
         outer_acc<2, 2>(DT, IT, accH0, lane);
-        __builtin_amdgcn_wave_barrier();
+        float dv[H];
+        mvt_mfma<6, false>(wh, DT, tile, lane, dv);                  // particles and (lane 40) the mean
         // d hid_obs[2] = sum over particles (and the mean) of dop (x) [relu(u) | 1]: rows 0, 1 of a tile (rows 2..15 hold stale du: their
         // products land in accumulator rows that are never stored)
         if (stage) {
@@ -651,13 +714,12 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             IT[27 * SP + lane] = act ? 1.0f : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
+        float wa[2][12];
+        mvt_fetch<12, 48>(wglob() + T_N, wa, lane);                  // the transposed product's weight fragments travel under the outer product
         outer_acc<3, 2>(DT, IT, accN, lane);
-        __builtin_amdgcn_wave_barrier();
         K13_STAMP(8)                                                 // d candidate, staging, outer product N
         float drh[H];
-#pragma unroll
-        for (int o = 0; o < H; ++o) drh[o] = 0.0f;
-        mvt<H, 48>(wptr() + T_N, [&](int o) -> float { return dan[o]; }, drh);
+        mvt_mfma<12, false>(wa, DT, tile, lane, drh);
         K13_STAMP(9)                                                 // transposed product N
         // ---- z, r = sigmoid(W_zr [h0, x] + b)
 #pragma unroll
@@ -674,10 +736,10 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? h0[k] : 0.0f;      // rows 24..27 still hold x | 1
         }
         __builtin_amdgcn_wave_barrier();
+        mvt_fetch<12, 48>(wglob() + T_ZR, wa, lane);
         outer_acc<3, 2>(DT, IT, accZR, lane);
-        __builtin_amdgcn_wave_barrier();
         K13_STAMP(10)                                                // d gates, staging, outer product ZR
-        mvt<H, 48>(wptr() + T_ZR, [&](int o) -> float { return dan[o]; }, dh);                  // dL / d (h1r of step t - 1), particle by particle
+        mvt_mfma<12, true>(wa, DT, tile, lane, dh);                  // dL / d (h1r of step t - 1), particle by particle
         K13_STAMP(11)                                                // transposed product ZR
     }
     K13_FLUSH
