@@ -227,14 +227,29 @@ __device__ __forceinline__ void mvt_fetch(const float* wt, float (&wa)[2][KK], i
     __builtin_amdgcn_sched_group_barrier(0x020, 2 * KK, 0);          // all requests go out HERE: left alone, the scheduler sinks each
 }                                                                    // load to its MFMA and waits for it there (24 exposed round trips)
 
+// The same for a FORWARD product out[o] = b[o] + sum over k < 4 KK of W[k][o] in[k][particle] (k-major table, row stride WS, 32 real or
+// zero columns; `in` staged like DT): A [o][k] = wt[k * WS + o], the bias rides in as the accumulators' initial value (bias4: the 4
+// consecutive outputs a lane holds per tile row block).
+template <int KK, int WS>
+__device__ __forceinline__ void mv_fetch(const float* wt, const float* bias, float (&wa)[2][KK], f4 (&b4)[2], int lane) {
+    typedef const __attribute__((address_space(1))) float* gptr_t;
+    typedef const __attribute__((address_space(1))) f4* gptr4_t;
+    const int c = lane & 15, q = lane >> 4;
+    gptr_t r0 = (gptr_t)wt + q * WS + c;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) { wa[0][kk] = r0[4 * kk * WS]; wa[1][kk] = r0[4 * kk * WS + 16]; }
+    b4[0] = *((gptr4_t)bias + q);
+    b4[1] = *((gptr4_t)bias + 4 + q);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 * KK + 2, 0);
+}
+
 template <int KK, bool ACC>
-__device__ __forceinline__ void mvt_mfma(const float (&wa)[2][KK], const float* DT, float* tile, int lane, float (&out)[H]) {
+__device__ __forceinline__ void mvt_mfma(const float (&wa)[2][KK], const float* DT, float* tile, int lane, float (&out)[H],
+                                         f4 init0 = f4{0, 0, 0, 0}, f4 init1 = f4{0, 0, 0, 0}) {
     const int c = lane & 15, q = lane >> 4;
     f4 acc[2][3];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f4{0, 0, 0, 0};
+    for (int nt = 0; nt < 3; ++nt) { acc[0][nt] = init0; acc[1][nt] = init1; }
     float bn[3];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) bn[nt] = DT[q * SP + 16 * nt + c];
@@ -551,6 +566,9 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         const float p1 = (lg - mx) - logf(se);
         const float pi = act ? expf(ps_t) : 0.0f;
 
+        float wf[2][6];
+        f4 bf[2];
+        { const float* wg = wglob(); mv_fetch<6, 32>(wg + T_H0, wg + T_H0B, wf, bf, lane); }   // hid_obs[0]'s fragments: requested a phase ahead of their product
         // ---- weighted mean of the resampled particles -> vec[0..23]
 #pragma unroll
         for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = pi * h1r[u];
@@ -568,10 +586,15 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float v[H];
 #pragma unroll
         for (int k = 0; k < H; ++k) v[k] = act ? h1r[k] : vec[k];
-        float uu[32];
+        // staged once for both the forward product below (matrix cores, as the transposed products) and hid_obs[0]'s weight gradient
+        if (stage) {
 #pragma unroll
-        for (int o = 0; o < 32; ++o) uu[o] = W[T_H0B + o];
-        mv<H, 32, H>(W + T_H0, [&](int k) -> float { return v[k]; }, uu);             // 24 of the 32 columns are real: 16 + 8
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act41 ? v[k] : 0.0f;
+            IT[H * SP + lane] = act41 ? 1.0f : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float uu[H];
+        mvt_mfma<6, false>(wf, IT, tile, lane, uu, bf[0], bf[1]);
         float out[2] = {W[T_H2 + 48], W[T_H2 + 49]};
 #pragma unroll
         for (int k = 0; k < H; ++k) {
@@ -613,8 +636,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         for (int k = 0; k < H; ++k) du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
         if (stage) {
 #pragma unroll
-            for (int k = 0; k < H; ++k) { DT[k * SP + lane] = act41 ? du[k] : 0.0f; IT[k * SP + lane] = act41 ? v[k] : 0.0f; }
-            IT[H * SP + lane] = act41 ? 1.0f : 0.0f;
+            for (int k = 0; k < H; ++k) DT[k * SP + lane] = act41 ? du[k] : 0.0f;        // IT still holds [v | 1]
         }
         __builtin_amdgcn_wave_barrier();
         float wh[2][6];
