@@ -162,7 +162,7 @@ constexpr int TAKERS_F = P * P / 4;         // [P][P] bytes: the lanes that resa
 constexpr int LDS_FLOATS = TILE_F + 2 * P /* forward: cdf (f64); backward: taker counts */ + 64 + DT_F + IT_F + PRE_F + TAKERS_F;
 
 // acc[ti][tj] += D^T I over the particles: DT [16 TI][SP] (row = output unit, column = particle), IT [16 TJ][SP]
-template <int TI, int TJ>
+template <int TI, int TJ, int KS = 11>          // KS k-steps of 4 particle columns: 11 with the mean "particle" (column 40), 10 without
 __device__ __forceinline__ void outer_acc(const float* DT, const float* IT, f4 (&acc)[TI][TJ], int lane) {
     const int c = lane & 15, q = lane >> 4;
     // the fragments of k-step s + 1 are read from LDS while the MFMAs of step s run: at one wave per SIMD every read that is waited for
@@ -173,13 +173,13 @@ __device__ __forceinline__ void outer_acc(const float* DT, const float* IT, f4 (
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) bn[tj] = IT[(16 * tj + c) * SP + q];
 #pragma unroll
-    for (int s = 0; s < 11; ++s) {
+    for (int s = 0; s < KS; ++s) {
         float a[TI], b[TJ];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) a[ti] = an[ti];
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) b[tj] = bn[tj];
-        if (s + 1 < 11) {
+        if (s + 1 < KS) {
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) an[ti] = DT[(16 * ti + c) * SP + 4 * (s + 1) + q];
 #pragma unroll
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             IT[27 * SP + lane] = act ? 1.0f : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
-        outer_acc<1, 2>(DT, IT, accO, lane);
+        outer_acc<1, 2, 10>(DT, IT, accO, lane);
         __builtin_amdgcn_wave_barrier();
         K13_STAMP(7)                                                 // fc_obs outer product
         // ---- h1 = (1 - z) n + z h0, n = tanh(mu + eps softplus(var))
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         __builtin_amdgcn_wave_barrier();
         float wa[2][12];
         mvt_fetch<12, 48>(wglob() + T_N, wa, lane);                  // the transposed product's weight fragments travel under the outer product
-        outer_acc<3, 2>(DT, IT, accN, lane);
+        outer_acc<3, 2, 10>(DT, IT, accN, lane);
         K13_STAMP(8)                                                 // d candidate, staging, outer product N
         float drh[H];
         mvt_mfma<12, false>(wa, DT, tile, lane, drh);
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         }
         __builtin_amdgcn_wave_barrier();
         mvt_fetch<12, 48>(wglob() + T_ZR, wa, lane);
-        outer_acc<3, 2>(DT, IT, accZR, lane);
+        outer_acc<3, 2, 10>(DT, IT, accZR, lane);
         K13_STAMP(10)                                                // d gates, staging, outer product ZR
         mvt_mfma<12, true>(wa, DT, tile, lane, dh);                  // dL / d (h1r of step t - 1), particle by particle
         K13_STAMP(11)                                                // transposed product ZR
