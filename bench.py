@@ -478,8 +478,9 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
                                        "avg_launch_ms": ms,
                                        "launches_timed": len(ds), "particle_steps_per_launch": sum(per_launch) / len(per_launch),
                                        "flops_per_launch": fl,
-                                       "note": "f32 vector/matrix peak (157.3 TFLOP/s); the products run as scalar-weight FMAs on the VALU "
-                                               "(measured f32 VALU peak 124 TFLOP/s), the weight-gradient reductions on the matrix cores"}
+                                       "note": "f32 vector/matrix peak (157.3 TFLOP/s); the forward walk's products run as scalar-weight FMAs on the "
+                                               "VALU (measured f32 VALU peak 124 TFLOP/s), the backward walk's transposed products and "
+                                               "weight-gradient reductions on the matrix cores"}
     del col, env, ag
     torch.cuda.empty_cache()
     return out

@@ -12,7 +12,8 @@
 // z, r, n and eps * softplus'(var) (15 KB per step; round 3 -- round 2 recomputed them from the stored input state, 21 % of the kernel),
 // then the backward kernel's wave walks it backwards: each step's gates are reloaded, the loss terms of the step are formed
 // and differentiated in registers, and the gradient flows to the previous step's particles through the resampling gather (an
-// LDS scatter-add) and the gates.  The small matrix products use wave-uniform weights through the scalar unit (as K11 / K12);
+// LDS scatter-add) and the gates.  The forward walk's matrix products use wave-uniform weights through the scalar unit (as K11 / K12);
+// the backward walk's (three transposed products and hid_obs' forward product) run on the matrix cores (mvt_fetch / mvt_mfma below);
 // the weight gradients are sums over particles of outer products: the per-particle factors are staged transposed in LDS and
 // accumulated on the matrix cores (v_mfma_f32_16x16x4_f32, contraction over the particles) in registers for the whole episode,
 // the two thin ones (fc_obs, hid_obs[2]) as rows of one more tile each.  Output: one gradient slab and one
@@ -72,8 +73,6 @@ __device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
 // The scalar-unit weight streams (wait -> request -> FMA blocks): csrc/rs_sstream.hpp
 template <int K, int OUTP, int OUTR = OUTP, typename F>
 __device__ __forceinline__ void mv(cmem_t W, F cval, float (&out)[OUTP]) { rs_ss_mv<K, OUTP, OUTR>(W, cval, out); }
-template <int K, int OUTP, int OUTR = OUTP, typename F>
-__device__ __forceinline__ void mvt(cmem_t W, F cval, float (&out)[K]) { rs_ss_mvt<K, OUTP, OUTR>(W, cval, out); }
 
 // value of lane L (a constant) in every lane: v_readlane_b32 (one instruction into an SGPR) instead of __shfl's LDS permute
 template <int L>
