@@ -60,6 +60,8 @@ struct PfArgs {
     const float* eps_in;      // [A][N][P][H] recorded reparameterisation noise   } REC instantiation only: the draws the reference
     const int32_t* idx_in;    // [A][N][P]    recorded resampling indices         } made (tests/golden/pfgru.npz, rada2c_core.npz)
     int N, A, carry;
+    int N2;                   // STEPS == 2 (rs_pfgru_pass): the sets still running at the second step (a prefix of the N of the first)
+    long long step_stride;    // STEPS == 2: elements between the two steps' rows of calls[]; obs / pred rows are 11 / 2 x that apart
     float alpha, floor_;      // soft-resampling alpha and (1 - alpha) / P, rounded to float32 as torch does for scalars
 };
 
@@ -96,7 +98,11 @@ __device__ __forceinline__ float pk_sum40(const float* v) {          // index or
     return s;
 }
 
-template <bool REC>
+// STEPS == 2 (rs_pfgru_pass only, one owner): two consecutive time steps of the carried sets from one launch, the particle set staying in
+// registers in between -- a launch costs ~17 us before its first round of workgroups is at speed (profiles/r03_k11_rounds.txt), a pass
+// has 120 of them.  The two steps are two COPIES of the step (compile-time unrolled): inside a runtime loop hipcc's schedule of the
+// weight stream fell apart, so the weight pointer is laundered between the copies.
+template <bool REC, int STEPS = 1>
 __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int groups) {
     __shared__ __align__(16) float smem[PK_SETS * PK_STRIDE];
     const int tid = threadIdx.x;
@@ -116,7 +122,6 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
     float *va = S + PK_VA, *vb = S + PK_VB, *vc = S + PK_VC, *vm = S + PK_VM;
     const bool act = set < PK_SETS;                                 // LDS writes allowed (the set's own area)
 
-    cmem_t W = as_cmem(a_.w + (size_t)own * PF_STRIDE);
     const size_t slot = (size_t)own * a_.N + n;
     // the particle sets are stored QUAD-major ([H / 4][P] float4 per set): a load / store instruction of a set's 40 lanes is 640 contiguous
     // bytes (a particle's 24 floats contiguous meant 16-byte pieces at a 96-byte stride; K13's scratch: 14 % of its forward walk)
@@ -127,181 +132,199 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         const float4 v = hp[(u / 4) * PF_P];
         h0[u] = v.x; h0[u + 1] = v.y; h0[u + 2] = v.z; h0[u + 3] = v.w;
     }
-    const float p0 = a_.p[slot * PF_P + q];
-    float x[PF_IN];
-    {
-        const float* o = a_.obs + ((size_t)n * a_.A + own) * RS_OBS_DIM;
-#pragma unroll
-        for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
-    }
-    // keys (pfgru.py: PredictorBank._key): kind 1 = reparameterisation noise, 2 = resampling uniforms
-    uint64_t k_res = 0, pk = 0;
-    if constexpr (!REC) {
-        const uint64_t kb = (uint64_t)a_.base[slot] * 1000003ull;
-        const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n]) * 8ull;
-        const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
-        k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
-        pk = k_eps * 1048583ull + (uint64_t)q * 4096ull;
-    }
-
-    // ---- gates: z | r = sigmoid(W_zr [h0, x] + b), consumed chunk by chunk (16 accumulators live, not 48: the kernel fits 4 waves
-    // per SIMD that way): z stays, r becomes r * h0 at once
-    float z[PF_H], rh[PF_H];
-    auto cv1 = [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
-    {
-        float acc[16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + o];
-        rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_ZR, cv1, acc);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) z[o] = pf_sigmoid(acc[o]);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 16 + o];
-        rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_ZR, cv1, acc);
-#pragma unroll
-        for (int o = 0; o < 8; ++o) { z[16 + o] = pf_sigmoid(acc[o]); rh[o] = pf_sigmoid(acc[8 + o]) * h0[o]; }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 32 + o];
-        rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_ZR, cv1, acc);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) rh[8 + o] = pf_sigmoid(acc[o]) * h0[8 + o];
-    }
-    // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b; the columns arrive as three chunks of
-    // [mu(8j .. 8j+7) | var(8j .. 8j+7)] (pfgru.py: pack_weights), each finishing eight units of h1
-    float h1[PF_H];
-    auto cv2 = [&](int k) -> float { return (k < PF_H) ? rh[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
-    auto candidate = [&](auto jc, const float (&acc)[16]) {
-        constexpr int J = decltype(jc)::value;
-        float eps8[8];
-#pragma unroll
-        for (int w = 0; w < 8; w += 2) {
-            const int u = 8 * J + w;
-            if constexpr (REC) {
-                eps8[w] = a_.eps_in[(slot * PF_P + q) * PF_H + u];
-                eps8[w + 1] = a_.eps_in[(slot * PF_P + q) * PF_H + u + 1];
-            } else {
-                // pfgru.py: hash_normal -- one hash per PAIR of units, Box-Muller's cosine for the even unit and sine for the odd one, on
-                // the hardware transcendentals (1 ulp each; v_cos_f32 / v_sin_f32 take revolutions: no range reduction): |error| ~ 1e-6
-                const uint64_t hx = pf_hash(pk + (uint64_t)u);
-                const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
-                const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
-                const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));
-                eps8[w] = r * __builtin_amdgcn_cosf(u2);
-                eps8[w + 1] = r * __builtin_amdgcn_sinf(u2);
-            }
+    float p0 = a_.p[slot * PF_P + q];
+    const int q_ = q, n_ = n;
+    auto step = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s_ = decltype(sc)::value;
+        const float* wl = a_.w + (size_t)own * PF_STRIDE;
+        int ql = q_, nl = n_;
+        // the second copy re-reads the weights and re-derives its keys and addresses, and not before the first one has produced its
+        // log-weights: nothing of it is requested, computed or kept early
+        if (STEPS > 1) asm volatile("" : "+s"(wl), "+v"(p0), "+v"(ql), "+v"(nl));
+        const int q = ql, n = nl;
+        cmem_t W = as_cmem(wl);
+        float x[PF_IN];
+        {
+            const float* o = a_.obs + (size_t)s_ * a_.step_stride * RS_OBS_DIM + ((size_t)n * a_.A + own) * RS_OBS_DIM;
+    #pragma unroll
+            for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
         }
+        // keys (pfgru.py: PredictorBank._key): kind 1 = reparameterisation noise, 2 = resampling uniforms
+        uint64_t k_res = 0, pk = 0;
+        if constexpr (!REC) {
+            const uint64_t kb = (uint64_t)a_.base[slot] * 1000003ull;
+            const uint64_t ctr8 = ((uint64_t)a_.episode[n] * 100003ull + (uint64_t)a_.calls[n + (size_t)s_ * a_.step_stride]) * 8ull;
+            const uint64_t k_eps = kb ^ ((ctr8 + 1ull) * 0xA24BAED4963EE407ull);
+            k_res = kb ^ ((ctr8 + 2ull) * 0xA24BAED4963EE407ull);
+            pk = k_eps * 1048583ull + (uint64_t)q * 4096ull;
+        }
+
+        // ---- gates: z | r = sigmoid(W_zr [h0, x] + b), consumed chunk by chunk (16 accumulators live, not 48: the kernel fits 4 waves
+        // per SIMD that way): z stays, r becomes r * h0 at once
+        float z[PF_H], rh[PF_H];
+        auto cv1 = [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
+        {
+            float acc[16];
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + o];
+            rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_ZR, cv1, acc);
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) z[o] = pf_sigmoid(acc[o]);
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 16 + o];
+            rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_ZR, cv1, acc);
+    #pragma unroll
+            for (int o = 0; o < 8; ++o) { z[16 + o] = pf_sigmoid(acc[o]); rh[o] = pf_sigmoid(acc[8 + o]) * h0[o]; }
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 32 + o];
+            rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_ZR, cv1, acc);
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) rh[8 + o] = pf_sigmoid(acc[o]) * h0[8 + o];
+        }
+        // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b; the columns arrive as three chunks of
+        // [mu(8j .. 8j+7) | var(8j .. 8j+7)] (pfgru.py: pack_weights), each finishing eight units of h1
+        float h1[PF_H];
+        auto cv2 = [&](int k) -> float { return (k < PF_H) ? rh[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
+        auto candidate = [&](auto jc, const float (&acc)[16]) {
+            constexpr int J = decltype(jc)::value;
+            float eps8[8];
+    #pragma unroll
+            for (int w = 0; w < 8; w += 2) {
+                const int u = 8 * J + w;
+                if constexpr (REC) {
+                    eps8[w] = a_.eps_in[(slot * PF_P + q) * PF_H + u];
+                    eps8[w + 1] = a_.eps_in[(slot * PF_P + q) * PF_H + u + 1];
+                } else {
+                    // pfgru.py: hash_normal -- one hash per PAIR of units, Box-Muller's cosine for the even unit and sine for the odd one, on
+                    // the hardware transcendentals (1 ulp each; v_cos_f32 / v_sin_f32 take revolutions: no range reduction): |error| ~ 1e-6
+                    const uint64_t hx = pf_hash(pk + (uint64_t)u);
+                    const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);          // (0, 1]
+                    const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1)
+                    const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));
+                    eps8[w] = r * __builtin_amdgcn_cosf(u2);
+                    eps8[w + 1] = r * __builtin_amdgcn_sinf(u2);
+                }
+            }
+    #pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int u = 8 * J + w;
+                const float eps = eps8[w];
+                const float var = acc[8 + w];
+                const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
+                const float y = acc[w] + eps * sp;
+                const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
+                h1[u] = (1.0f - z[u]) * nv + z[u] * h0[u];
+            }
+        };
+        {
+            float acc[16];
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + o];
+            rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_N, cv2, acc);
+            candidate(std::integral_constant<int, 0>{}, acc);
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 16 + o];
+            rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_N, cv2, acc);
+            candidate(std::integral_constant<int, 1>{}, acc);
+    #pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 32 + o];
+            rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_N, cv2, acc);
+            candidate(std::integral_constant<int, 2>{}, acc);
+        }
+        // ---- observation likelihood, log-softmax over the set's particles
+        float lg = W[PF_OB];
+    #pragma unroll
+        for (int k = 0; k < PF_K; ++k) lg = fmaf(W[PF_O + k], (k < PF_H) ? h1[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H], lg);
+        lg += p0;
+        if (act) va[q] = lg;
+        __syncthreads();                                                // 1
+        const float mx = pk_max40(va);
+        const float e1 = expf(lg - mx);
+        if (act) vb[q] = e1;
+        __syncthreads();                                                // 2
+        float p1 = (lg - mx) - logf(pk_sum40(vb));
+        // ---- soft resampling: indices by inverse CDF of alpha * w + (1 - alpha) / P
+        const float al = a_.alpha, floor_ = a_.floor_;
+        if (act) {
+            va[q] = al * expf(p1) + floor_;
+            vc[q] = p1;
+    #pragma unroll
+            for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = h1[u];
+        }
+        __syncthreads();                                                // 3
+        int idx = 0;
+        if constexpr (REC) {
+            idx = min(max(a_.idx_in[slot * PF_P + q], 0), PF_P - 1);
+        } else {
+            double run = 0.0, mine = 0.0;                               // float64 prefix sums in index order (torch.cumsum of the .double() weights)
+    #pragma unroll
+            for (int i = 0; i < PF_P / 4; ++i) {
+                const float4 t = reinterpret_cast<const float4*>(va)[i];
+                run += (double)t.x; mine = (4 * i == q) ? run : mine;
+                run += (double)t.y; mine = (4 * i + 1 == q) ? run : mine;
+                run += (double)t.z; mine = (4 * i + 2 == q) ? run : mine;
+                run += (double)t.w; mine = (4 * i + 3 == q) ? run : mine;
+            }
+            if (act) cdf[q] = mine / run;
+            __syncthreads();                                            // 4
+            const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)q * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
+    #pragma unroll
+            for (int j = 0; j < PF_P / 2; ++j) {                        // searchsorted(..., right=True)
+                const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
+                idx += (c2.x <= ru) ? 1 : 0;
+                idx += (c2.y <= ru) ? 1 : 0;
+            }
+            idx = min(idx, PF_P - 1);
+        }
+    #pragma unroll
+        for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
+        float pn = expf(vc[idx]);
+        pn = logf(pn / (al * pn + floor_));
+        if (act) vb[q] = pn;
+        __syncthreads();                                                // 5
+        const float mx2 = pk_max40(vb);
+        const float e2 = expf(pn - mx2);
+        if (act) va[q] = e2;
+        __syncthreads();                                                // 6
+        p1 = pn - (logf(pk_sum40(va)) + mx2);
+        if (s_ == STEPS - 1 && a_.carry && live) {
+            float4* hw = reinterpret_cast<float4*>(a_.h + slot * PF_P * PF_H) + q;
+    #pragma unroll
+            for (int u = 0; u < PF_H; u += 4) hw[(u / 4) * PF_P] = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
+            a_.p[slot * PF_P + q] = p1;
+        }
+        // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
+        const float wgt = expf(p1);
+        if (act) {
+    #pragma unroll
+            for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = wgt * h1[u];      // every lane gathered its row before barrier 5
+        }
+        __syncthreads();                                                // 7
+        const int ul = q < PF_H ? q : PF_H - 1;
+        float mean = 0.0f;
+        for (int j = 0; j < PF_P; ++j) mean += tile[j * PF_ROW + ul];
+        if (act && q < PF_H) vm[q] = mean;
+        __syncthreads();                                                // 8
+        const float* wg = a_.w + (size_t)own * PF_STRIDE;
+        float t = wg[PF_H0B + ul];
+        for (int k = 0; k < PF_H; ++k) t = fmaf(wg[PF_H0 + k * 24 + ul], vm[k], t);
+        t = fmaxf(t, 0.0f);
+        if (act && q < PF_H) { vb[q] = wg[PF_H2 + ul] * t; vc[q] = wg[PF_H2 + 24 + ul] * t; }      // vb / vc: last read before barrier 6
+        __syncthreads();                                                // 9
+        if (live && q == 0 && (s_ == 0 || n < a_.N2)) {
+            float o0 = 0.0f, o1 = 0.0f;
+            for (int k = 0; k < PF_H; ++k) { o0 += vb[k]; o1 += vc[k]; }
+            float* out = a_.pred + (size_t)s_ * a_.step_stride * 2 + ((size_t)n * a_.A + own) * 2;
+            out[0] = fmaxf(o0 + wg[PF_H2B], 0.0f); out[1] = fmaxf(o1 + wg[PF_H2B + 1], 0.0f);
+        }
+        if (s_ + 1 < STEPS) {                                       // the resampled set is the next step's input (no HBM round trip)
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const int u = 8 * J + w;
-            const float eps = eps8[w];
-            const float var = acc[8 + w];
-            const float sp = (var > 20.0f) ? var : 0.69314718f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(1.44269504f * var));   // F.softplus
-            const float y = acc[w] + eps * sp;
-            const float nv = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * y));                          // tanh
-            h1[u] = (1.0f - z[u]) * nv + z[u] * h0[u];
+            for (int u = 0; u < PF_H; ++u) h0[u] = h1[u];
+            p0 = p1;
         }
     };
-    {
-        float acc[16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + o];
-        rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_N, cv2, acc);
-        candidate(std::integral_constant<int, 0>{}, acc);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 16 + o];
-        rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_N, cv2, acc);
-        candidate(std::integral_constant<int, 1>{}, acc);
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 32 + o];
-        rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_N, cv2, acc);
-        candidate(std::integral_constant<int, 2>{}, acc);
-    }
-    // ---- observation likelihood, log-softmax over the set's particles
-    float lg = W[PF_OB];
-#pragma unroll
-    for (int k = 0; k < PF_K; ++k) lg = fmaf(W[PF_O + k], (k < PF_H) ? h1[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H], lg);
-    lg += p0;
-    if (act) va[q] = lg;
-    __syncthreads();                                                // 1
-    const float mx = pk_max40(va);
-    const float e1 = expf(lg - mx);
-    if (act) vb[q] = e1;
-    __syncthreads();                                                // 2
-    float p1 = (lg - mx) - logf(pk_sum40(vb));
-    // ---- soft resampling: indices by inverse CDF of alpha * w + (1 - alpha) / P
-    const float al = a_.alpha, floor_ = a_.floor_;
-    if (act) {
-        va[q] = al * expf(p1) + floor_;
-        vc[q] = p1;
-#pragma unroll
-        for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = h1[u];
-    }
-    __syncthreads();                                                // 3
-    int idx = 0;
-    if constexpr (REC) {
-        idx = min(max(a_.idx_in[slot * PF_P + q], 0), PF_P - 1);
-    } else {
-        double run = 0.0, mine = 0.0;                               // float64 prefix sums in index order (torch.cumsum of the .double() weights)
-#pragma unroll
-        for (int i = 0; i < PF_P / 4; ++i) {
-            const float4 t = reinterpret_cast<const float4*>(va)[i];
-            run += (double)t.x; mine = (4 * i == q) ? run : mine;
-            run += (double)t.y; mine = (4 * i + 1 == q) ? run : mine;
-            run += (double)t.z; mine = (4 * i + 2 == q) ? run : mine;
-            run += (double)t.w; mine = (4 * i + 3 == q) ? run : mine;
-        }
-        if (act) cdf[q] = mine / run;
-        __syncthreads();                                            // 4
-        const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)q * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
-#pragma unroll
-        for (int j = 0; j < PF_P / 2; ++j) {                        // searchsorted(..., right=True)
-            const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
-            idx += (c2.x <= ru) ? 1 : 0;
-            idx += (c2.y <= ru) ? 1 : 0;
-        }
-        idx = min(idx, PF_P - 1);
-    }
-#pragma unroll
-    for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
-    float pn = expf(vc[idx]);
-    pn = logf(pn / (al * pn + floor_));
-    if (act) vb[q] = pn;
-    __syncthreads();                                                // 5
-    const float mx2 = pk_max40(vb);
-    const float e2 = expf(pn - mx2);
-    if (act) va[q] = e2;
-    __syncthreads();                                                // 6
-    p1 = pn - (logf(pk_sum40(va)) + mx2);
-    if (a_.carry && live) {
-        float4* hw = reinterpret_cast<float4*>(a_.h + slot * PF_P * PF_H) + q;
-#pragma unroll
-        for (int u = 0; u < PF_H; u += 4) hw[(u / 4) * PF_P] = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
-        a_.p[slot * PF_P + q] = p1;
-    }
-    // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
-    const float wgt = expf(p1);
-    if (act) {
-#pragma unroll
-        for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = wgt * h1[u];      // every lane gathered its row before barrier 5
-    }
-    __syncthreads();                                                // 7
-    const int ul = q < PF_H ? q : PF_H - 1;
-    float mean = 0.0f;
-    for (int j = 0; j < PF_P; ++j) mean += tile[j * PF_ROW + ul];
-    if (act && q < PF_H) vm[q] = mean;
-    __syncthreads();                                                // 8
-    const float* wg = a_.w + (size_t)own * PF_STRIDE;
-    float t = wg[PF_H0B + ul];
-    for (int k = 0; k < PF_H; ++k) t = fmaf(wg[PF_H0 + k * 24 + ul], vm[k], t);
-    t = fmaxf(t, 0.0f);
-    if (act && q < PF_H) { vb[q] = wg[PF_H2 + ul] * t; vc[q] = wg[PF_H2 + 24 + ul] * t; }      // vb / vc: last read before barrier 6
-    __syncthreads();                                                // 9
-    if (live && q == 0) {
-        float o0 = 0.0f, o1 = 0.0f;
-        for (int k = 0; k < PF_H; ++k) { o0 += vb[k]; o1 += vc[k]; }
-        float* out = a_.pred + ((size_t)n * a_.A + own) * 2;
-        out[0] = fmaxf(o0 + wg[PF_H2B], 0.0f); out[1] = fmaxf(o1 + wg[PF_H2B + 1], 0.0f);
-    }
+    step(std::integral_constant<int, 0>{});
+    if constexpr (STEPS > 1) step(std::integral_constant<int, 1>{});      // (a `#pragma unroll` loop over the steps is NOT unrolled by hipcc)
 }
 
 // reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: h0 ~ U[0,1) from the hash (kind 0), p0 = log(1 / P).
@@ -395,7 +418,7 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
                   int32_t num_agents, rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || num_envs < 1 || num_agents < 1)
         return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0,
+    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0, 0, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
@@ -408,7 +431,18 @@ int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, co
     for (int t = 0; t < steps; ++t)
         if (alive[t] < 0 || alive[t] > episodes || (t > 0 && alive[t] > alive[t - 1])) return RS_ERR_INVALID_ARG;
     int rc = rs_pfgru_reset(h, p, base_key, episode, calls, nullptr, episodes, 1, stream);
-    for (int t = 0; t < steps && rc == RS_OK && alive[t] > 0; ++t)
+    int t = 0;
+    // steps in PAIRS while the second one still has episodes (the two-step instantiation: the sets alive at t, of which the first
+    // alive[t + 1] also take -- and report -- step t + 1; the others' sets are dead afterwards, their extra step is discarded)
+    for (; t + 1 < steps && rc == RS_OK && alive[t + 1] > 0; t += 2) {
+        PfArgs a{weights, obs + (size_t)t * episodes * RS_OBS_DIM, h, p, base_key, episode, calls + (size_t)t * episodes, nullptr,
+                 pred + (size_t)t * episodes * 2, nullptr, nullptr, alive[t], 1, 1, alive[t + 1], (long long)episodes,
+                 (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
+        const int groups = (alive[t] + PK_SETS - 1) / PK_SETS;
+        hipLaunchKernelGGL((rs_pfgru_kernel<false, 2>), dim3((unsigned)groups), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
+        if (hipGetLastError() != hipSuccess) rc = RS_ERR_HIP;
+    }
+    for (; t < steps && rc == RS_OK && alive[t] > 0; ++t)
         rc = rs_pfgru_step(weights, obs + (size_t)t * episodes * RS_OBS_DIM, h, p, base_key, episode, calls + (size_t)t * episodes, nullptr, 1, alpha,
                            pred + (size_t)t * episodes * 2, alive[t], 1, stream);
     return rc;
@@ -418,7 +452,7 @@ int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, flo
                            const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
                            rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !eps || !idx || !pred || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0,
+    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0, 0, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
