@@ -327,9 +327,10 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
                   const int64_t* calls, const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs,
                   int32_t num_agents, rs_stream_t stream);
 /* A whole no-grad pass over an episode-major batch in ONE call: grad_step's PFGRU loop over an episode (RADA2C_core.py:555-558) for E
- * episodes of one predictor.  Enqueues rs_pfgru_reset and then one rs_pfgru_step per time step t < steps on `stream` (carried particle
- * sets, the step counter of launch t = calls[t][.]), each over the first alive[t] episodes (episodes sorted by descending length: the ones
- * still running are a prefix).  obs [steps][E][11], calls [steps][E], pred [steps][E][2], alive: HOST array [steps].  Exists so that the
+ * episodes of one predictor.  Enqueues rs_pfgru_reset and then the time steps t < steps on `stream`, four per launch (carried particle
+ * sets staying in registers inside a launch; the step counter of step t = calls[t][.]; results identical to one rs_pfgru_step per t), each
+ * launch over the first alive[t] episodes of its first step (episodes sorted by descending length: the ones still running are a prefix;
+ * an episode that ends inside a launch's group of steps reports only its own steps).  obs [steps][E][11], calls [steps][E], pred [steps][E][2], alive: HOST array [steps].  Exists so that the
  * ~120 launches of a pass cost one library call: the policy loop of update_rada2c issues 40 such passes per update. */
 int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, const int64_t* base_key, const int64_t* episode,
                   const int64_t* calls, double alpha, float* pred, const int32_t* alive, int32_t steps, int32_t episodes, rs_stream_t stream);

@@ -60,8 +60,8 @@ struct PfArgs {
     const float* eps_in;      // [A][N][P][H] recorded reparameterisation noise   } REC instantiation only: the draws the reference
     const int32_t* idx_in;    // [A][N][P]    recorded resampling indices         } made (tests/golden/pfgru.npz, rada2c_core.npz)
     int N, A, carry;
-    int N2;                   // STEPS == 2 (rs_pfgru_pass): the sets still running at the second step (a prefix of the N of the first)
-    long long step_stride;    // STEPS == 2: elements between the two steps' rows of calls[]; obs / pred rows are 11 / 2 x that apart
+    int Ns[3];                // STEPS > 1 (rs_pfgru_pass): the sets still running at the launch's 2nd .. 4th step (prefixes of N, descending)
+    long long step_stride;    // STEPS > 1: elements between two steps' rows of calls[]; obs / pred rows are 11 / 2 x that apart
     float alpha, floor_;      // soft-resampling alpha and (1 - alpha) / P, rounded to float32 as torch does for scalars
 };
 
@@ -73,6 +73,10 @@ constexpr int PF_ROW = PF_H + 1;                                   // odd row st
 // putting them into the one-set-per-wave kernel); the lanes gained are 1.5x.  Four waves per workgroup = one per SIMD, three workgroups per
 // CU at 168 VGPRs (nine sets on 384 threads left the second workgroup without room on two of the SIMDs: 188 us per step).
 constexpr int PK_SETS = 6, PK_NT = 256;
+#ifndef RS_K11_PASS_STEPS
+#define RS_K11_PASS_STEPS 4        // time steps per launch of rs_pfgru_pass (1 .. 4).  A/B, 120-step pass of 16.5 k episodes inside the policy
+                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61 (127 VGPRs, 0 / 0 / 20 B of scratch)
+#endif
 // LDS of one set (floats): tile [40][25] | cdf 40 x f64 | va [40] | vb [40] | vc [40] | vm [24] (+ pad); the stride is 12 (mod 32) banks so
 // that the up to three sets a wave touches read different banks
 constexpr int PK_TILE = 0, PK_CDF = PF_P * PF_ROW, PK_VA = PK_CDF + 2 * PF_P, PK_VB = PK_VA + PF_P, PK_VC = PK_VB + PF_P,
@@ -98,10 +102,12 @@ __device__ __forceinline__ float pk_sum40(const float* v) {          // index or
     return s;
 }
 
-// STEPS == 2 (rs_pfgru_pass only, one owner): two consecutive time steps of the carried sets from one launch, the particle set staying in
+// STEPS > 1 (rs_pfgru_pass only, one owner): consecutive time steps of the carried sets from one launch, the particle set staying in
 // registers in between -- a launch costs ~17 us before its first round of workgroups is at speed (profiles/r03_k11_rounds.txt), a pass
-// has 120 of them.  The two steps are two COPIES of the step (compile-time unrolled): inside a runtime loop hipcc's schedule of the
-// weight stream fell apart, so the weight pointer is laundered between the copies.
+// has 120 steps.  The steps are explicit COPIES of the step (a generic lambda instantiated per step index): inside a runtime loop -- and
+// hipcc keeps a `#pragma unroll` loop over the steps a loop -- the schedule of the weight stream falls apart (412 B of scratch, 204 SGPR
+// spills).  Between the copies the weight pointer and the lane indices are laundered together with the log-weight
+// the previous copy produced, so that nothing of the next copy is requested, computed or kept early (without: 360 B of scratch).
 template <bool REC, int STEPS = 1>
 __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int groups) {
     __shared__ __align__(16) float smem[PK_SETS * PK_STRIDE];
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         t = fmaxf(t, 0.0f);
         if (act && q < PF_H) { vb[q] = wg[PF_H2 + ul] * t; vc[q] = wg[PF_H2 + 24 + ul] * t; }      // vb / vc: last read before barrier 6
         __syncthreads();                                                // 9
-        if (live && q == 0 && (s_ == 0 || n < a_.N2)) {
+        if (live && q == 0 && (s_ == 0 || n < a_.Ns[s_ > 0 ? s_ - 1 : 0])) {
             float o0 = 0.0f, o1 = 0.0f;
             for (int k = 0; k < PF_H; ++k) { o0 += vb[k]; o1 += vc[k]; }
             float* out = a_.pred + (size_t)s_ * a_.step_stride * 2 + ((size_t)n * a_.A + own) * 2;
@@ -325,6 +331,8 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
     };
     step(std::integral_constant<int, 0>{});
     if constexpr (STEPS > 1) step(std::integral_constant<int, 1>{});      // (a `#pragma unroll` loop over the steps is NOT unrolled by hipcc)
+    if constexpr (STEPS > 2) step(std::integral_constant<int, 2>{});
+    if constexpr (STEPS > 3) step(std::integral_constant<int, 3>{});
 }
 
 // reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: h0 ~ U[0,1) from the hash (kind 0), p0 = log(1 / P).
@@ -418,7 +426,7 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
                   int32_t num_agents, rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || num_envs < 1 || num_agents < 1)
         return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0, 0, 0,
+    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0}, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
@@ -432,14 +440,16 @@ int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, co
         if (alive[t] < 0 || alive[t] > episodes || (t > 0 && alive[t] > alive[t - 1])) return RS_ERR_INVALID_ARG;
     int rc = rs_pfgru_reset(h, p, base_key, episode, calls, nullptr, episodes, 1, stream);
     int t = 0;
-    // steps in PAIRS while the second one still has episodes (the two-step instantiation: the sets alive at t, of which the first
-    // alive[t + 1] also take -- and report -- step t + 1; the others' sets are dead afterwards, their extra step is discarded)
-    for (; t + 1 < steps && rc == RS_OK && alive[t + 1] > 0; t += 2) {
+    // steps in groups of PASS_STEPS while the group's last one still has episodes (the multi-step instantiation: the sets alive at t, of
+    // which the first alive[t + s] also take -- and report -- step t + s; the others' sets are dead by then, their extra steps are discarded)
+    constexpr int PASS_STEPS = RS_K11_PASS_STEPS;
+    for (; t + PASS_STEPS - 1 < steps && rc == RS_OK && alive[t + PASS_STEPS - 1] > 0; t += PASS_STEPS) {
         PfArgs a{weights, obs + (size_t)t * episodes * RS_OBS_DIM, h, p, base_key, episode, calls + (size_t)t * episodes, nullptr,
-                 pred + (size_t)t * episodes * 2, nullptr, nullptr, alive[t], 1, 1, alive[t + 1], (long long)episodes,
+                 pred + (size_t)t * episodes * 2, nullptr, nullptr, alive[t], 1, 1, {0, 0, 0}, (long long)episodes,
                  (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
+        for (int s_ = 1; s_ < PASS_STEPS; ++s_) a.Ns[s_ - 1] = alive[t + s_];
         const int groups = (alive[t] + PK_SETS - 1) / PK_SETS;
-        hipLaunchKernelGGL((rs_pfgru_kernel<false, 2>), dim3((unsigned)groups), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
+        hipLaunchKernelGGL((rs_pfgru_kernel<false, PASS_STEPS>), dim3((unsigned)groups), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
         if (hipGetLastError() != hipSuccess) rc = RS_ERR_HIP;
     }
     for (; t < steps && rc == RS_OK && alive[t] > 0; ++t)
@@ -452,7 +462,7 @@ int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, flo
                            const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
                            rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !eps || !idx || !pred || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0, 0, 0,
+    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0}, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
