@@ -60,7 +60,7 @@ struct PfArgs {
     const float* eps_in;      // [A][N][P][H] recorded reparameterisation noise   } REC instantiation only: the draws the reference
     const int32_t* idx_in;    // [A][N][P]    recorded resampling indices         } made (tests/golden/pfgru.npz, rada2c_core.npz)
     int N, A, carry;
-    int Ns[3];                // STEPS > 1 (rs_pfgru_pass): the sets still running at the launch's 2nd .. 4th step (prefixes of N, descending)
+    int Ns[5];                // STEPS > 1 (rs_pfgru_pass): the sets still running at the launch's 2nd .. 6th step (prefixes of N, descending)
     long long step_stride;    // STEPS > 1: elements between two steps' rows of calls[]; obs / pred rows are 11 / 2 x that apart
     float alpha, floor_;      // soft-resampling alpha and (1 - alpha) / P, rounded to float32 as torch does for scalars
 };
@@ -74,8 +74,9 @@ constexpr int PF_ROW = PF_H + 1;                                   // odd row st
 // CU at 168 VGPRs (nine sets on 384 threads left the second workgroup without room on two of the SIMDs: 188 us per step).
 constexpr int PK_SETS = 6, PK_NT = 256;
 #ifndef RS_K11_PASS_STEPS
-#define RS_K11_PASS_STEPS 4        // time steps per launch of rs_pfgru_pass (1 .. 4).  A/B, 120-step pass of 16.5 k episodes inside the policy
-                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61 (127 VGPRs, 0 / 0 / 20 B of scratch)
+#define RS_K11_PASS_STEPS 4        // time steps per launch of rs_pfgru_pass (1 .. 6).  A/B, 120-step pass of 16.5 k episodes inside the policy
+                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61, 6 = 12.8 (127 VGPRs, 0 / 0 / 20 / 20 B of scratch; the
+                                   // code of a copy is 44 KB; 8 copies do not compile: "illegal VGPR to SGPR copy")
 #endif
 // LDS of one set (floats): tile [40][25] | cdf 40 x f64 | va [40] | vb [40] | vc [40] | vm [24] (+ pad); the stride is 12 (mod 32) banks so
 // that the up to three sets a wave touches read different banks
@@ -146,7 +147,8 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         int ql = q_, nl = n_;
         // the second copy re-reads the weights and re-derives its keys and addresses, and not before the first one has produced its
         // log-weights: nothing of it is requested, computed or kept early
-        if (STEPS > 1) asm volatile("" : "+s"(wl), "+v"(p0), "+v"(ql), "+v"(nl));
+        // (the single hashing step takes the laundering too: 125 VGPRs and no scratch instead of 128 + 40 B, 105 -> 98 us with carried sets)
+        if constexpr (!REC || STEPS > 1) asm volatile("" : "+s"(wl), "+v"(p0), "+v"(ql), "+v"(nl));
         const int q = ql, n = nl;
         cmem_t W = as_cmem(wl);
         float x[PF_IN];
@@ -333,6 +335,8 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
     if constexpr (STEPS > 1) step(std::integral_constant<int, 1>{});      // (a `#pragma unroll` loop over the steps is NOT unrolled by hipcc)
     if constexpr (STEPS > 2) step(std::integral_constant<int, 2>{});
     if constexpr (STEPS > 3) step(std::integral_constant<int, 3>{});
+    if constexpr (STEPS > 4) step(std::integral_constant<int, 4>{});
+    if constexpr (STEPS > 5) step(std::integral_constant<int, 5>{});
 }
 
 // reset_hidden (RADTEAM_core.py:2030-2033) for the masked envs: h0 ~ U[0,1) from the hash (kind 0), p0 = log(1 / P).
@@ -426,7 +430,7 @@ int rs_pfgru_step(const float* weights, const float* obs, float* h, float* p, co
                   int32_t num_agents, rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !base_key || !episode || !calls || !pred || num_envs < 1 || num_agents < 1)
         return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0}, 0,
+    PfArgs a{weights, obs, h, p, base_key, episode, calls, mask, pred, nullptr, nullptr, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0, 0, 0}, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<false>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
@@ -443,9 +447,10 @@ int rs_pfgru_pass(const float* weights, const float* obs, float* h, float* p, co
     // steps in groups of PASS_STEPS while the group's last one still has episodes (the multi-step instantiation: the sets alive at t, of
     // which the first alive[t + s] also take -- and report -- step t + s; the others' sets are dead by then, their extra steps are discarded)
     constexpr int PASS_STEPS = RS_K11_PASS_STEPS;
+    static_assert(PASS_STEPS >= 1 && PASS_STEPS <= 6, "copies of the step per launch");
     for (; t + PASS_STEPS - 1 < steps && rc == RS_OK && alive[t + PASS_STEPS - 1] > 0; t += PASS_STEPS) {
         PfArgs a{weights, obs + (size_t)t * episodes * RS_OBS_DIM, h, p, base_key, episode, calls + (size_t)t * episodes, nullptr,
-                 pred + (size_t)t * episodes * 2, nullptr, nullptr, alive[t], 1, 1, {0, 0, 0}, (long long)episodes,
+                 pred + (size_t)t * episodes * 2, nullptr, nullptr, alive[t], 1, 1, {0, 0, 0, 0, 0}, (long long)episodes,
                  (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
         for (int s_ = 1; s_ < PASS_STEPS; ++s_) a.Ns[s_ - 1] = alive[t + s_];
         const int groups = (alive[t] + PK_SETS - 1) / PK_SETS;
@@ -462,7 +467,7 @@ int rs_pfgru_step_recorded(const float* weights, const float* obs, float* h, flo
                            const uint8_t* mask, int32_t carry_hidden, double alpha, float* pred, int32_t num_envs, int32_t num_agents,
                            rs_stream_t stream) {
     if (!weights || !obs || !h || !p || !eps || !idx || !pred || num_envs < 1 || num_agents < 1) return RS_ERR_INVALID_ARG;
-    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0}, 0,
+    PfArgs a{weights, obs, h, p, nullptr, nullptr, nullptr, mask, pred, eps, idx, num_envs, num_agents, carry_hidden ? 1 : 0, {0, 0, 0, 0, 0}, 0,
              (float)alpha, (float)((1.0 - alpha) / (double)PF_P)};
     const int groups = (num_envs + PK_SETS - 1) / PK_SETS;
     hipLaunchKernelGGL(rs_pfgru_kernel<true>, dim3((unsigned)(groups * num_agents)), dim3(PK_NT), 0, static_cast<hipStream_t>(stream), a, groups);
