@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         float x[PF_IN];
         {
             const float* o = a_.obs + (size_t)s_ * a_.step_stride * RS_OBS_DIM + ((size_t)n * a_.A + own) * RS_OBS_DIM;
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < PF_IN; ++k) x[k] = o[k];
         }
         // keys (pfgru.py: PredictorBank._key): kind 1 = reparameterisation noise, 2 = resampling uniforms
@@ -173,20 +173,20 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         auto cv1 = [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
         {
             float acc[16];
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + o];
             rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_ZR, cv1, acc);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) z[o] = pf_sigmoid(acc[o]);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 16 + o];
             rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_ZR, cv1, acc);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 8; ++o) { z[16 + o] = pf_sigmoid(acc[o]); rh[o] = pf_sigmoid(acc[8 + o]) * h0[o]; }
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_ZRB + 32 + o];
             rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_ZR, cv1, acc);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) rh[8 + o] = pf_sigmoid(acc[o]) * h0[8 + o];
         }
         // ---- candidate: n = tanh(mu + eps * softplus(var)), [mu | var] = W_n [r * h0, x] + b; the columns arrive as three chunks of
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         auto candidate = [&](auto jc, const float (&acc)[16]) {
             constexpr int J = decltype(jc)::value;
             float eps8[8];
-    #pragma unroll
+#pragma unroll
             for (int w = 0; w < 8; w += 2) {
                 const int u = 8 * J + w;
                 if constexpr (REC) {
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
                     eps8[w + 1] = r * __builtin_amdgcn_sinf(u2);
                 }
             }
-    #pragma unroll
+#pragma unroll
             for (int w = 0; w < 8; ++w) {
                 const int u = 8 * J + w;
                 const float eps = eps8[w];
@@ -226,22 +226,22 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         };
         {
             float acc[16];
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + o];
             rs_ss_mv_cols<PF_K, 48, 0, 16>(W + PF_N, cv2, acc);
             candidate(std::integral_constant<int, 0>{}, acc);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 16 + o];
             rs_ss_mv_cols<PF_K, 48, 16, 16>(W + PF_N, cv2, acc);
             candidate(std::integral_constant<int, 1>{}, acc);
-    #pragma unroll
+#pragma unroll
             for (int o = 0; o < 16; ++o) acc[o] = W[PF_NB + 32 + o];
             rs_ss_mv_cols<PF_K, 48, 32, 16>(W + PF_N, cv2, acc);
             candidate(std::integral_constant<int, 2>{}, acc);
         }
         // ---- observation likelihood, log-softmax over the set's particles
         float lg = W[PF_OB];
-    #pragma unroll
+#pragma unroll
         for (int k = 0; k < PF_K; ++k) lg = fmaf(W[PF_O + k], (k < PF_H) ? h1[k < PF_H ? k : 0] : x[k < PF_H ? 0 : k - PF_H], lg);
         lg += p0;
         if (act) va[q] = lg;
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         if (act) {
             va[q] = al * expf(p1) + floor_;
             vc[q] = p1;
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = h1[u];
         }
         __syncthreads();                                                // 3
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
             idx = min(max(a_.idx_in[slot * PF_P + q], 0), PF_P - 1);
         } else {
             double run = 0.0, mine = 0.0;                               // float64 prefix sums in index order (torch.cumsum of the .double() weights)
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < PF_P / 4; ++i) {
                 const float4 t = reinterpret_cast<const float4*>(va)[i];
                 run += (double)t.x; mine = (4 * i == q) ? run : mine;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
             if (act) cdf[q] = mine / run;
             __syncthreads();                                            // 4
             const double ru = (double)(pf_hash(k_res * 1048583ull + (uint64_t)q * 4096ull) >> 11) * (1.0 / 9007199254740992.0);
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < PF_P / 2; ++j) {                        // searchsorted(..., right=True)
                 const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
                 idx += (c2.x <= ru) ? 1 : 0;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
             }
             idx = min(idx, PF_P - 1);
         }
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
         float pn = expf(vc[idx]);
         pn = logf(pn / (al * pn + floor_));
@@ -297,14 +297,14 @@ __global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int group
         p1 = pn - (logf(pk_sum40(va)) + mx2);
         if (s_ == STEPS - 1 && a_.carry && live) {
             float4* hw = reinterpret_cast<float4*>(a_.h + slot * PF_P * PF_H) + q;
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < PF_H; u += 4) hw[(u / 4) * PF_P] = make_float4(h1[u], h1[u + 1], h1[u + 2], h1[u + 3]);
             a_.p[slot * PF_P + q] = p1;
         }
         // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
         const float wgt = expf(p1);
         if (act) {
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = wgt * h1[u];      // every lane gathered its row before barrier 5
         }
         __syncthreads();                                                // 7
