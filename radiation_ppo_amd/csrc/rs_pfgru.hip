@@ -75,7 +75,7 @@ constexpr int PF_ROW = PF_H + 1;                                   // odd row st
 constexpr int PK_SETS = 6, PK_NT = 256;
 #ifndef RS_K11_PASS_STEPS
 #define RS_K11_PASS_STEPS 4        // time steps per launch of rs_pfgru_pass (1 .. 6).  A/B, 120-step pass of 16.5 k episodes inside the policy
-                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61, 6 = 12.8 (127 VGPRs, 0 / 0 / 20 / 20 B of scratch; the
+                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61, 5 = 12.76, 6 = 12.8 (127 VGPRs, 0 / 0 / 20 / .. B of scratch; the
                                    // code of a copy is 44 KB; 8 copies do not compile: "illegal VGPR to SGPR copy")
 #endif
 // LDS of one set (floats): tile [40][25] | cdf 40 x f64 | va [40] | vb [40] | vc [40] | vm [24] (+ pad); the stride is 12 (mod 32) banks so
