@@ -441,11 +441,13 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     _lib.EVENTS = {}
     tc = tu = 0.0
     stops, loops = [], []
+    k13_units, k11_units = [], []                  # particle-steps of every timed K13 launch / K11 pass, in launch order (as the event pairs)
     t0 = time.perf_counter()
     for _ in range(iters):
         a = time.perf_counter(); col.collect(); torch.cuda.synchronize(); b = time.perf_counter()
         res = col.update(); torch.cuda.synchronize(); c = time.perf_counter()
         tc += b - a; tu += c - b
+        k13_units += ag[0].k13_particle_steps; k11_units += ag[0].k11_particle_steps
         stops.append(res[0].stop_iteration)
         loops.append(1e3 * getattr(ag[0], "policy_loop_seconds", 0.0))
     dt = time.perf_counter() - t0
@@ -468,7 +470,7 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
         # weight-gradient outer products 3 366), 40 particles per episode-step.  Round 2 counted 12 180: it
         # included the forward cell RECOMPUTED in the backward walk, which round 3 replaced by stored gates -- not algorithmic work.
         ms = sum(ds) / len(ds)
-        per_launch = ag[0].k13_particle_steps[-len(ds):]                 # one count per launch, in launch order (as the event pairs)
+        per_launch = k13_units[-len(ds):]                                # one count per launch, in launch order (as the event pairs)
         fl = 2.0 * 9561 * sum(per_launch) / len(per_launch)               # mean FLOP per launch; achieved = total FLOP / total time
         tf = fl / (ms * 1e-3) / 1e12
         t13, src13 = unit_traffic("rs_pfgru_train_kernel")
@@ -481,6 +483,23 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
                                        "note": "f32 vector/matrix peak (157.3 TFLOP/s); the forward walk's products run as scalar-weight FMAs on the "
                                                "VALU (measured f32 VALU peak 124 TFLOP/s), the backward walk's transposed products and "
                                                "weight-gradient reductions on the matrix cores"}
+    if kp and k11_units:
+        # K11 (rs_pfgru_kernel, four time steps per launch, ~30 launches per pass): 2 619 multiply-adds per particle-step -- the cell's
+        # two gate products 27 -> 48, the observation-likelihood row 27 -> 1 (csrc/rs_pfgru.hip header); hid_obs runs once per SET and
+        # step and is not counted.  Time = the HIP events around every rs_pfgru_pass call of the timed policy loops (side stream).
+        n = min(len(kp), len(k11_units))
+        fl = 2.0 * 2619 * sum(k11_units[-n:]) / n
+        ms = sum(kp[-n:]) / n
+        tf = fl / (ms * 1e-3) / 1e12
+        t11, src11 = unit_traffic("rs_pfgru_kernel")
+        out["roofline_pfgru_step"] = {"bound": "mfma", "kernel": "rs_pfgru_kernel (K11), per pass of the policy loop (rs_pfgru_pass)", "achieved": tf,
+                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                      "traffic": None if t11 is None else t11 * sum(k11_units[-n:]) / n / 40.0, "traffic_source": src11,
+                                      "avg_launch_ms": ms, "launches_timed": n, "particle_steps_per_launch": sum(k11_units[-n:]) / n,
+                                      "flops_per_launch": fl,
+                                      "note": "a 'launch' here is one PASS (reset + ~30 four-step launches over every episode of the epoch); f32 "
+                                              "vector/matrix peak 157.3 TFLOP/s, the cell runs as scalar-weight FMAs on the VALU (measured f32 VALU "
+                                              "peak 124 TFLOP/s); algorithmic FLOP, not issue slots"}
     del col, env, ag
     torch.cuda.empty_cache()
     return out

@@ -27,6 +27,19 @@
 
 #include "../../include/radsearch.h"
 
+// Diagnostic build only (-DRS_CNN_STAMPS, scripts/cnn_stamps.py): s_memtime stamps at the phase boundaries of an image round, summed per
+// wave and added to a device table [kernel][wave][phase] when the workgroup leaves.  Read the SHARES (the stamps pin the schedule).
+#ifdef RS_CNN_STAMPS
+__device__ unsigned long long rs_cnn_cyc[2][8][8];
+#define CNN_DECL unsigned long long cs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long cs_t = __builtin_amdgcn_s_memtime();
+#define CNN_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long cs_n = __builtin_amdgcn_s_memtime(); cs_acc[i] += cs_n - cs_t; cs_t = cs_n; __builtin_amdgcn_sched_barrier(0); }
+#define CNN_FLUSH(k) if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 8; ++q) atomicAdd(&rs_cnn_cyc[k][threadIdx.x >> 6][q], cs_acc[q]); }
+#else
+#define CNN_DECL
+#define CNN_STAMP(i)
+#define CNN_FLUSH(k)
+#endif
+
 namespace {
 
 #ifndef CNN_BWD_WAVES
@@ -213,13 +226,16 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
     const long long rounds = (in.S + FW_IMG - 1) / FW_IMG;
     FwFetch f;
     if ((long long)blockIdx.x < rounds) fw_fetch<CIN>(in, (long long)blockIdx.x * FW_IMG, img, f);
+    CNN_DECL
     for (long long rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
         const long long s = rd * FW_IMG + img;
         const bool own = tid < FW_OWN && s < in.S;
         const int loc = f.loc, pc = f.pc;
         fw_stage(f, xp);
         if (rd + gridDim.x < rounds) fw_fetch<CIN>(in, (rd + gridDim.x) * FW_IMG, img, f);      // next round: in flight during the compute
+        CNN_STAMP(0)
         __syncthreads();
+        CNN_STAMP(1)
         if (own) {
             // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
             float acc[4][C1];
@@ -280,7 +296,7 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
                             }
                     }
                 };
-                stamp(loc, stl + 72);
+                if (loc >= 0) stamp(loc, stl + 72);      // -1 = no position recorded yet (fresh maps): contributes nothing, as in K10's gather
                 if (pc >= 0) stamp(pc, stl);
             }
             float pbest[C1];
@@ -306,7 +322,9 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
                 *reinterpret_cast<uint2*>(amax + ((size_t)s * PC + cell) * C1) = make_uint2(pidx[0], pidx[1]);
             }
         }
+        CNN_STAMP(2)
         __syncthreads();
+        CNN_STAMP(3)
         if (own) {
             // ---- conv2 + bias + ReLU
             float acc2[C2];
@@ -331,8 +349,11 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
             }
             if (relu_mask) relu_mask[(size_t)s * PC + cell] = (uint16_t)live;       // what backward needs of a2: its sign
         }
+        CNN_STAMP(4)
         __syncthreads();
+        CNN_STAMP(5)
     }
+    CNN_FLUSH(0)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +426,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         }
     };
     if ((long long)blockIdx.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, blockIdx.x, f); if (CNN_BWD_PREFETCH) fetch_acts(blockIdx.x); }
+    CNN_DECL
     for (long long s = blockIdx.x; s < in.S; s += gridDim.x) {
         const int loc = f.loc, pc = f.pc;
         if (!CNN_BWD_PREFETCH) fetch_acts(s);
@@ -421,7 +443,9 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
         }
         if (s + gridDim.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
+        CNN_STAMP(0)
         __syncthreads();
+        CNN_STAMP(1)
         // ---- dW2[co][n] += sum_px dZ2[co][px] * P1patch[px][n]   (matrix cores; k-steps interleaved over the 3 waves)
 #if !(defined(CNN_ABL) && CNN_ABL == 3)
         {
@@ -454,6 +478,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
             }
         }
 #endif
+        CNN_STAMP(2)
         // ---- dP1 = conv2^T(dZ2), gated by the pool's ReLU (P1 > 0).  The sum over the 16 output channels is split between the pixel
         // threads (waves 0-2: co 0..12, 117 taps each) and the helper wave (co 13..15 for up to three pixels per lane, 81 taps):
         // with all 144 taps on the 169 pixel threads the fourth wave sat idle for the longest phase of the kernel (28 % of it).  The
@@ -494,7 +519,9 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 }
             }
         }
+        CNN_STAMP(3)
         __syncthreads();
+        CNN_STAMP(4)
         // ---- dW1[co1][c0][:] += g[co1][cell] * x[c0] window at the cell's arg-max pixel (no branch on g == 0: a dead
         // cell adds zeros; the phase is instruction-issue bound, so the index work is shared by CG channels)
 #if !(defined(CNN_ABL) && CNN_ABL == 1)
@@ -534,6 +561,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
             }
         }
 #endif
+        CNN_STAMP(5)
         if (CIN == 6 && tid < 2 * C1 * 9) {
             // one-hot input at (r, c): tap (ky, kx) of conv1 meets it at output pixel (r - ky + 1, c - kx + 1); that pixel carries
             // gradient iff it is its pool window's arg-max for channel co
@@ -548,8 +576,11 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 }
             }
         }
+        CNN_STAMP(6)
         __syncthreads();
+        CNN_STAMP(7)
     }
+    CNN_FLUSH(1)
     // ---- workgroup reduction (fixed order) -> slab row
     __syncthreads();
     float* red = smem;                               // aliases the image buffers: [NGRP][NCOMBO][AW], [NWAVE][16][80], [2][8][9]
@@ -617,6 +648,14 @@ inline int cnn_grid(K kernel, int threads, size_t lds, long long S) {
 }  // namespace
 
 extern "C" {
+
+#ifdef RS_CNN_STAMPS
+int rs_debug_cnn_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[2 * 8 * 8] = {0};
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(rs_cnn_cyc), z, sizeof(z)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rs_cnn_cyc), sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int32_t rs_cnn_trunk_slab_row(int32_t in_channels) { return C1 * in_channels * 9 + C1 + C2 * 72 + C2; }
 int32_t rs_cnn_trunk_slab_rows(int64_t num_samples, int32_t in_channels) {

@@ -126,6 +126,14 @@ __global__ void __launch_bounds__(64) rs_maps_update_kernel(RsMapsParams M, RsPa
         if (a < A) {
             int cx = (int)(((double)E.ax[(size_t)a * E.N + n] * E.scale) * M.ra);
             int cy = (int)(((double)E.ay[(size_t)a * E.N + n] * E.scale) * M.ra);
+            if (E.coord_noise) {
+                // the reference bins what the agent OBSERVES, int(single_observation[1] * resolution_accuracy) (RADTEAM_core.py:705-711),
+                // and with coord_noise the observed coordinates carry N(0, 5 cm) (rad_search_env.py:569-580): take the cell from the
+                // observation row (its float32; the exact position is used otherwise so that no rounding of the row can move a cell)
+                const float* o = obs + ((size_t)n * A + a) * RS_OBS_DIM;
+                cx = (int)((double)o[1] * M.ra);
+                cy = (int)((double)o[2] * M.ra);
+            }
             // a NEGATIVE index is legal numpy: map[-k] is the k-th cell from the end.  Without enforced walls a detector left of /
             // below the area lands there (what the 147 x 147 map's extra cells absorb, RADTEAM_core.py:1727-1738)
             if (cx < 0) cx += M.X;

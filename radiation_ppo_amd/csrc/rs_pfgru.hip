@@ -4,16 +4,25 @@
 // PFGRUCell.forward (:1586-1631) with observation_likelihood (:1633-1641), soft resampling (PFRNNBaseCell.resampling
 // :1466-1515) and reparameterize (:1517-1530): 40 particles x 24 hidden units, alpha 0.7, tanh.
 //
-// Mapping: one wave per (owner, env), one particle per lane (40 of 64 lanes).  A particle's 24 hidden units, its gates and
-// its candidate state live in the lane's registers; the three small matrix products (27 -> 48, 27 -> 48, 27 -> 1) are
-// per-lane FMA chains whose weights are wave-uniform (one owner per wave): they arrive through the scalar unit
-// (s_load_dwordx16 from the constant address space -> SGPR operand of v_fma), costing neither VGPRs nor LDS bandwidth.
-// What couples the particles -- log-softmax, the resampling CDF, the gather of resampled particles, the weighted mean --
-// goes through wave reductions and a 4.6 KB per-wave LDS tile.  Random draws (reparameterisation noise, resampling
-// uniforms) are the counter hash of radiation_ppo_amd/pfgru.py evaluated in the kernel: nothing is read but the
-// observation row, the particle set (3.9 KB) and the 13.5 KB of weights (L2 / scalar cache resident).
+// Mapping: six (owner, env) particle sets per 256-thread workgroup, one particle per lane (240 of 256 lanes carry a particle; one
+// owner per workgroup).  A particle's 24 hidden units, its gates and its candidate state live in the lane's registers; the three
+// small matrix products (27 -> 48, 27 -> 48, 27 -> 1) are per-lane FMA chains whose weights are workgroup-uniform: they arrive
+// through the scalar unit (s_load_dwordx16 from the constant address space -> SGPR operand of v_fma, ordered wait -> request ->
+// FMA by rs_sstream.hpp), costing neither VGPRs nor LDS bandwidth.  Both gate products are consumed chunk by chunk (16 live
+// accumulators: 125-128 VGPRs, four waves per SIMD, no scratch).  A set's 40 lanes straddle waves, so what couples its particles --
+// two log-softmaxes, the float64 resampling CDF, the gather of resampled particles, the weighted mean, the hid_obs head -- goes
+// through LDS and workgroup barriers; every lane reads the set's 40 values back and reduces them in index order (deterministic,
+// independent of which sets share a workgroup).  Random draws (reparameterisation noise: one splitmix64 hash per PAIR of units ->
+// Box-Muller cos / sin; resampling uniforms) are the counter hash of radiation_ppo_amd/pfgru.py evaluated in the kernel: nothing is
+// read but the observation row, the quad-major particle set (3.9 KB) and the 13.9 KB of weights (scalar cache / L2 resident).
 //
-// Bound: VALU issue (2 700 FMAs + 24 hashes + ~120 transcendentals per lane); 16 384 waves per step at config 4.
+// Instantiations: <false, 1> the collectors' step (rs_pfgru_step); <false, 4> FOUR time steps per launch as four straight-line
+// copies of the step with the particle set in registers in between (rs_pfgru_pass: the policy loop's 120-step passes in 30
+// launches); <true, 1> the same arithmetic with noise / resampling indices read from buffers (the reference's recorded runs).
+//
+// Bound: VALU issue.  Algorithmic work 2 619 multiply-adds per particle-step (2 x 27 x 48 + 27); the kernel issues ~2 700 FMAs +
+// 12 hashes + ~120 hardware transcendentals per lane and step.  16 384 sets x 40 particles at config 4: 98 us per step =
+// 35 TFLOP/s of algorithmic work = 0.22 of the 157.3 TFLOP/s f32 peak (bench.py: roofline_pfgru_step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

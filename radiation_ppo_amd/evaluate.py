@@ -100,9 +100,20 @@ def _pack(env_sets: Dict[str, tuple], runs: int, with_obstacles: bool, device):
 @torch.no_grad()
 def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montecarlo_runs: int = 100, steps_per_episode: int = 120,
                           obstruction_count: int = 0, enforce_grid_boundaries: bool = True, seed: int = 0,
-                          device: str = "cuda:0", return_actions: bool = False, falloff: str = "reference"):
+                          device: str = "cuda:0", return_actions: bool = False, falloff: str = "reference",
+                          carry_hidden_across_runs: bool = False):
     """EpisodeRunner.run for every saved environment at once.  Returns (List[MonteCarloResults] in set order, summary
-    dict with the statistics `evaluate.py:776-828` prints); with return_actions also the [steps, E*R] action log."""
+    dict with the statistics `evaluate.py:776-828` prints); with return_actions also the [steps, E*R] action log.
+
+    carry_hidden_across_runs (recurrent policies only): the reference creates `hiddens` ONCE per EpisodeRunner.run
+    (evaluate.py:357) and between Monte-Carlo runs resets only the statistics buffer (:455-470), so run k + 1 of an
+    environment starts from the GRU / PFGRU state run k ended in.  True reproduces that (one lane per saved environment, its
+    runs one after the other: `_run_sequential`); False gives every (environment, run) pair its own lane and a fresh hidden
+    state -- R times fewer lock-steps, a deviation from the reference for 'rnn' policies (none for 'ff': no hidden state).
+    `evaluate_PPO` uses True."""
+    if carry_hidden_across_runs and hasattr(agent.agent, "gru_cell"):
+        return _run_sequential(agent, env_sets, montecarlo_runs, steps_per_episode, obstruction_count, enforce_grid_boundaries, seed,
+                               device, falloff, return_actions)
     E, R, L = len(env_sets), montecarlo_runs, steps_per_episode
     N = E * R
     dev = torch.device(device)
@@ -164,6 +175,90 @@ def run_test_environments(agent: VecAgentPPO, env_sets: Dict[str, tuple], montec
     if return_actions:
         return out, summary, torch.stack(log).cpu().numpy()
     return out, summary
+
+
+@torch.no_grad()
+def _run_sequential(agent, env_sets, montecarlo_runs, steps_per_episode, obstruction_count, enforce_grid_boundaries, seed, device, falloff,
+                    return_actions=False):
+    """EpisodeRunner.run (evaluate.py:333-476) with the reference's hidden-state lifetime: one lane per saved environment, its
+    Monte-Carlo runs in sequence.  When a run ends (source found or steps_per_episode reached) the lane's env is refreshed
+    (:455), its statistics buffer restarts on the fresh observation (:462-468) -- and the GRU state and the PFGRU's particle
+    set are left as the finished run left them (`hiddens` is assigned once, :357).  With return_actions the third result is the
+    [lock-steps, E] action log with -1 where a lane had finished all its runs."""
+    from .pfgru import PredictorBank, hash_uniform
+    E, R, L = len(env_sets), montecarlo_runs, steps_per_episode
+    dev = torch.device(device)
+    with_obs = obstruction_count != 0
+    vec = RadSearchVec(E, number_agents=1, obstruction_count=obstruction_count, enforce_grid_boundaries=enforce_grid_boundaries,
+                       seed=seed, device=device, falloff=falloff)
+    keys, src, det, inten, bkg, nob, rects = _pack(env_sets, 1, with_obs, dev)
+    vec.reset()
+    obs = vec.refresh(src, det, inten, bkg, nob, rects)[0].clone()
+    stat = DeviceWelford((E, 1), dev)
+    stat.update(obs[..., 0])
+    bank = PredictorBank(E, 1, hidden_size=agent.agent.rec, seed=seed, carry_hidden=True, device=dev,
+                         impl="hip" if agent.agent.fused_pfgru else "torch")
+    bank.cells[0] = agent.agent.model
+    bank.reset()
+    gk = (bank._base[0] * 1000003 + 5).view(-1, 1) * 1048583 + torch.arange(agent.agent.hid, dtype=torch.int64, device=dev).view(1, -1)
+    hid = agent.agent.gru_h0(hash_uniform(gk)).contiguous()
+    fused = agent.agent.fused_policy and hasattr(agent, "policy_step_hip")
+    run = torch.zeros(E, dtype=torch.int64, device=dev)
+    steps = torch.zeros(E, dtype=torch.int32, device=dev)
+    ret = torch.zeros(E, dtype=torch.float32, device=dev)
+    rec_len = torch.zeros(E, R, dtype=torch.int32, device=dev)
+    rec_ret = torch.zeros(E, R, dtype=torch.float32, device=dev)
+    rec_suc = torch.zeros(E, R, dtype=torch.bool, device=dev)
+    lane = torch.arange(E, device=dev)
+    u = torch.empty(E, 1, dtype=torch.float32, device=dev)
+    act8 = torch.empty(E, 1, dtype=torch.int8, device=dev)
+    a = torch.empty(E, dtype=torch.int64, device=dev)
+    it = 0
+    log = []
+    while True:
+        active = run < R
+        if it % 16 == 0 and not bool(active.any()):            # one host read per 16 lock-steps
+            break
+        it += 1
+        x = obs.clone()
+        stat.standardize(obs[..., 0], out=x[..., 0])
+        vec.action_uniforms(u)
+        if fused:
+            agent.policy_step_hip(x[:, 0].contiguous(), bank.predict(x, mask=active)[:, 0].contiguous(), hid, u=u[:, 0].contiguous(),
+                                  h_out=hid, act=a)
+        else:
+            logits, _, hid = agent.agent.policy_step(x[:, 0], bank.predict(x, mask=active)[:, 0], hid)
+            cdf = torch.cumsum(torch.softmax(logits, dim=-1), dim=-1)
+            a = (cdf[:, :-1] <= u[:, 0].unsqueeze(-1)).sum(dim=-1)
+        act8[:, 0] = torch.where(active, a, torch.full_like(a, 8)).to(torch.int8)       # lanes with all runs done idle in place
+        if return_actions:
+            log.append(torch.where(active, a, torch.full_like(a, -1)))
+        obs_n, rew, _, done, _ = vec.step(act8)
+        ret += torch.where(active, rew[:, 0], torch.zeros_like(rew[:, 0]))
+        steps += active.int()
+        found = done[:, 0].bool() & active
+        over = found | ((steps == L) & active)
+        stat.update(obs_n[..., 0], mask=active)                                         # :392-397 (before the episode-over test)
+        slot = run.clamp(max=R - 1)
+        rec_len[lane, slot] = torch.where(over, steps, rec_len[lane, slot])
+        rec_ret[lane, slot] = torch.where(over, ret, rec_ret[lane, slot])
+        rec_suc[lane, slot] = torch.where(over, found, rec_suc[lane, slot])
+        run += over.long()
+        again = over & (run < R)                                                        # :455-468: refresh, statistics restart
+        obs_r = vec.refresh(src, det, inten, bkg, nob, rects, mask=again.to(torch.uint8))[0]
+        stat.reset(again)
+        stat.update(obs_r[..., 0], mask=again)
+        obs = torch.where(again.view(E, 1, 1), obs_r, obs_n).clone()
+        steps.masked_fill_(over, 0)
+        ret.masked_fill_(over, 0.0)
+    flags = vec.error_flags()
+    if flags:
+        raise RuntimeError(f"RadSearch env error flags 0x{flags:x}")
+    rep = lambda t: t.repeat_interleave(R)
+    out = _collect_results(keys, E, R, rec_len.reshape(-1), rec_ret.reshape(-1), rec_suc.reshape(-1), rep(inten), rep(bkg))
+    if return_actions:
+        return out, summarize(out), torch.stack(log).cpu().numpy()
+    return out, summarize(out)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -354,7 +449,8 @@ class evaluate_PPO:
             from .rada2c import RNNAgentPPO
             ag = RNNAgentPPO(id=0, device=dev)
             ag.load(agent_dir(0))                                       # pyt_save/model.pt (epoch_logger.py:216-284)
-            self.results, self.summary = run_test_environments(ag, sets, **common)
+            self.results, self.summary = run_test_environments(ag, sets, carry_hidden_across_runs=bool(kw.get("carry_hidden_across_runs", True)),
+                                                               **common)
         else:
             ag = VecAgentPPO(id=0, device=dev)
             d = agent_dir(0)

@@ -360,16 +360,51 @@ def host_read(t: torch.Tensor) -> List[float]:
 _HOST_READ: Dict[Any, Any] = {}
 
 
+# Every key of the reference's ppo_kwargs (algos/multiagent/main.py:574-596; AgentPPO's fields, ppo.py:505-600).  A constructor of this
+# build names the ones that configure its path; of the rest it accepts exactly those listed as `no_effect` there (each with the reason
+# in its docstring) and raises on anything else -- a misspelt or unsupported option must not vanish into **kwargs.
+REFERENCE_PPO_KWARGS = frozenset({
+    "observation_space", "bp_args", "steps_per_epoch", "steps_per_episode", "number_of_agents", "env_height", "actor_critic_args",
+    "actor_critic_architecture", "minibatch", "train_pi_iters", "train_v_iters", "train_pfgru_iters", "actor_learning_rate",
+    "critic_learning_rate", "pfgru_learning_rate", "gamma", "alpha", "clip_ratio", "target_kl", "lam", "GlobalCriticOptimizer"})
+
+
+def reject_unknown_kwargs(where: str, extra: Dict[str, Any], no_effect) -> None:
+    """`extra`: what a constructor received beyond its named parameters."""
+    unknown = sorted(set(extra) - set(no_effect))
+    if unknown:
+        raise TypeError(f"{where}: unexpected keyword argument(s) {unknown}; accepted without effect on this path: {sorted(no_effect)}")
+
+
+def check_minibatch(minibatch: Any) -> int:
+    if not isinstance(minibatch, int) or isinstance(minibatch, bool) or minibatch < 1:
+        raise ValueError(f"minibatch must be a positive int (ppo.py:580), got {minibatch!r}")
+    return minibatch
+
+
 class VecAgentPPO:
-    """One agent id's networks + optimiser; the vectorised counterpart of AgentPPO (ppo.py:505-1355)."""
+    """One agent id's networks + optimiser; the vectorised counterpart of AgentPPO (ppo.py:505-1355).
+
+    `minibatch` (ppo.py:580) is accepted and validated but changes nothing here, exactly as in the reference: this path is the
+    update_rada2c loss form, and update_rada2c assigns `minibatch` (ppo.py:1159-1160) and never reads it -- every episode of the epoch
+    enters every iteration (`ep_select` takes `min_iterations = len(ep_form)` episodes, :1183).  Keys of the reference's ppo_kwargs
+    without a counterpart on this path (_NO_EFFECT: the PFGRU's and the CNN critic's settings, `actor_critic_args` of the GRU core,
+    `train_v_iters` / `critic_learning_rate` -- one optimiser trains actor and critic, ppo.py:1256-1258) are accepted; others raise."""
+
+    _NO_EFFECT = ("bp_args", "env_height", "actor_critic_args", "train_pfgru_iters", "pfgru_learning_rate", "seed")
 
     def __init__(self, id: int, observation_space: int = 11, action_space: int = 8, steps_per_epoch: int = 480,
                  steps_per_episode: int = 120, number_of_agents: int = 1, actor_critic_architecture: str = "ff",
                  train_pi_iters: int = 40, train_v_iters: int = 40, actor_learning_rate: float = 3e-4,
                  critic_learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 0.0, clip_ratio: float = 0.2,
-                 target_kl: float = 0.07, lam: float = 0.9, device="cuda:0", **unused: Any):
+                 target_kl: float = 0.07, lam: float = 0.9, minibatch: int = 1, GlobalCriticOptimizer=None, device="cuda:0",
+                 **other: Any):
         if actor_critic_architecture not in ("ff", "mlp"):
             raise ValueError("Unsupported Neural Network type requested")   # ppo.py:666-667
+        if GlobalCriticOptimizer is not None:
+            raise Exception("No global critic option for RAD-A2C")          # ppo.py:651-652
+        reject_unknown_kwargs("VecAgentPPO", other, self._NO_EFFECT)
+        self.minibatch = check_minibatch(minibatch)
         self.id = id
         self.device = torch.device(device)
         self.gamma, self.lam, self.alpha = gamma, lam, alpha

@@ -22,8 +22,30 @@ import torch.distributed as dist
 from . import _lib
 from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps, actor_stack_from
-from .pfgru import PredictorBank
-from .ppo import EpochStats, RolloutBuffer, UpdateResult, _world, host_read, normalize_advantages, reduce_grads_and_stats
+from .pfgru import PredictorBank, hash_bits, hash_uniform
+from .ppo import (EpochStats, RolloutBuffer, UpdateResult, _world, check_minibatch, host_read, normalize_advantages,
+                  reduce_grads_and_stats, reject_unknown_kwargs)
+
+
+def minibatch_weights(complete_len: torch.Tensor, T: int, minibatch: int, key: torch.Tensor, n_total: int) -> torch.Tensor:
+    """sample() of update_agent's 'cnn' branch (ppo.py:754-766) for every env (= rank of the reference) at once: env n draws
+    k_n = int(ep_len_n / minibatch) of the indexes [0, ep_len_n) uniformly WITHOUT replacement (np.random.choice(..., replace=False)),
+    ep_len_n = the summed length of its complete episodes; the losses are then means over the drawn indexes (:934-940) and over ranks
+    (mpi_avg_grads).  Returns w [T, N] float32: 1 / (k_n n_total) on the drawn samples of env n, 0 elsewhere.
+
+    The draw: every index gets a counter-hash uniform (key [N] int64 = one value per env and draw, so the result does not depend on
+    how the envs are sharded over GPUs); the k_n smallest are taken -- a uniformly distributed k-subset.  minibatch = 1 is every
+    index (a permutation; the mean does not see the order)."""
+    N = complete_len.shape[0]
+    dev = complete_len.device
+    k = torch.div(complete_len, minibatch, rounding_mode="floor")
+    tt = torch.arange(T, device=dev, dtype=torch.int64).view(T, 1)
+    valid = tt < complete_len.view(1, N)
+    u = hash_uniform(hash_bits(key.view(1, N)) + tt)
+    u = torch.where(valid, u, torch.full_like(u, 2.0))
+    thr = u.sort(dim=0).values.gather(0, (k - 1).clamp(min=0).view(1, N))
+    sel = (u <= thr) & valid & (k > 0).view(1, N)
+    return sel.float() / (k.clamp(min=1).view(1, N).float() * n_total)
 
 
 class ActorLoss(torch.autograd.Function):
@@ -53,10 +75,23 @@ class ActorLoss(torch.autograd.Function):
 
 
 class CNNAgentPPO:
+    """AgentPPO, 'cnn' branch.  `minibatch` (ppo.py:580, :754-766) IS effective here: every actor iteration draws
+    int(ep_len / minibatch) sample indexes per env, the critic iterations reuse the last draw (minibatch_weights above).  Keys of the
+    reference's ppo_kwargs without a counterpart on this path are accepted (_NO_EFFECT: the reference's own 'cnn' branch does not train
+    the PFGRU -- "TODO get PFGRU working with RAD-TEAM", ppo.py:849-852 -- and `actor_critic_args` describes its CNNBase, whose sizes
+    come from the env here; `use_predictor` / `predictor_hidden_size` are read by train_PPO for the collector); others raise."""
+
+    _NO_EFFECT = ("bp_args", "env_height", "actor_critic_args", "train_pfgru_iters", "pfgru_learning_rate", "use_predictor",
+                  "predictor_hidden_size")
+
     def __init__(self, id: int, map_dim=(27, 27), action_space: int = 8, train_pi_iters: int = 40, train_v_iters: int = 40,
                  actor_learning_rate: float = 3e-4, critic_learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 0.0,
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, GlobalCritic: Optional[CNNCritic] = None,
-                 GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 524288, **unused: Any):
+                 GlobalCriticOptimizer: Optional[torch.optim.Optimizer] = None, device="cuda:0", chunk: int = 524288,
+                 observation_space: int = 11, steps_per_epoch: int = 480, steps_per_episode: int = 120, number_of_agents: int = 1,
+                 minibatch: int = 1, seed: int = 0, **other: Any):
+        reject_unknown_kwargs("CNNAgentPPO", other, self._NO_EFFECT)
+        self.minibatch, self.seed = check_minibatch(minibatch), int(seed)
         self.id = id
         self.map_dim = tuple(map_dim)
         self.device = torch.device(device)
@@ -100,13 +135,16 @@ class CNNAgentPPO:
         logp = logp_all.gather(-1, a.unsqueeze(-1)).squeeze(-1)
         return a, logp
 
-    def update_agent(self, actor_in, critic_in, act, adv, ret, logp_old, w, update_critic: bool) -> UpdateResult:
+    def update_agent(self, actor_in, critic_in, act, adv, ret, logp_old, w, update_critic: bool, w_for=None) -> UpdateResult:
         """actor_in(lo, hi) / critic_in(lo, hi) describe the inputs of samples [lo, hi) (see _logits / _values);
-        w sums to 1 over the global batch."""
+        w sums to 1 over the global batch.  w_for(kk) -> the weights of actor iteration kk (minibatch > 1: a fresh draw per
+        iteration, ppo.py:831; the critic loop keeps the LAST draw, :861-864)."""
         M = act.shape[0]
         thr = 1.5 * self.target_kl
         kk, kl_reached, last = 0, False, None
         while not kl_reached and kk < self.train_pi_iters:                      # ppo.py:825-846
+            if w_for is not None:
+                w = w_for(kk)
             self.pi_optimizer.zero_grad(set_to_none=True)
             stats = torch.zeros(4, dtype=torch.float64, device=self.device)
             for lo in range(0, M, self.chunk):
@@ -228,6 +266,7 @@ class CNNCollector:
         self._u = torch.empty(self.N, self.A, dtype=torch.float32, device=dev)
         self._act8 = torch.empty(self.N, self.A, dtype=torch.int8, device=dev)
         self.complete_len = torch.zeros(self.N, dtype=torch.int64, device=dev)
+        self.epoch = 0                                  # updates done: keys the minibatch draws (and travels with resume.pt)
         # one lock-step of the loop is ~60 small launches (maps, 5 trunk + head evaluations, sampling, env step, bootstrap
         # round, resets): launch bound.  The step is therefore captured ONCE into a HIP graph and replayed T - 1 times per
         # epoch (the epoch's last step, which raises epoch_end, runs eagerly).  Everything a step reads or writes lives at a
@@ -360,13 +399,14 @@ class CNNCollector:
         if self.obs is None:
             self.start()
         return dict(env=self.env.snapshot(), maps=self.maps.snapshot(), steps_in_ep=self.steps_in_ep.clone(), ep_ret=self.ep_ret.clone(),
-                    obs=self.obs.clone(), predictor=None if self.predictor is None else self.predictor.resume_state())
+                    obs=self.obs.clone(), predictor=None if self.predictor is None else self.predictor.resume_state(), epoch=self.epoch)
 
     def load_resume_state(self, st: Dict[str, Any]) -> None:
         if self.obs is None:
             self.start()
         self.env.restore(st["env"]); self.maps.restore(st["maps"])
         self.steps_in_ep.copy_(st["steps_in_ep"]); self.ep_ret.copy_(st["ep_ret"]); self.obs.copy_(st["obs"])
+        self.epoch = int(st.get("epoch", 0))
         if self.predictor is not None and st.get("predictor") is not None:
             self.predictor.load_resume_state(st["predictor"])
 
@@ -391,11 +431,20 @@ class CNNCollector:
         cells = self.cells.view(T * N, self.A)
         pcells = self.pcells.view(T * N, self.A)
         out = {}
+        env_ids = int(self.env.cfg.env_id_base) + torch.arange(N, device=buf.rew.device, dtype=torch.int64)
         for a, ag in self.agents.items():
             adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
             actor_in = lambda lo, hi, a=a: (shared[lo:hi], cells[lo:hi], pcells[lo:hi], a)
             critic_in = lambda lo, hi: (shared[lo:hi],)
             upd_c = (not ag.global_critic) or a == 0
+            w_for = None
+            if ag.minibatch > 1:                                        # sample() (ppo.py:754-766): a fresh draw per actor iteration
+                if int(self.complete_len.min().item()) < ag.minibatch:
+                    # the reference fails here too: int(ep_len / minibatch) = 0 indexes -> torch.stack([]) (ppo.py:936)
+                    raise ValueError(f"minibatch {ag.minibatch} exceeds the {int(self.complete_len.min().item())} complete-episode samples of an env")
+                base = (ag.seed * 4294967296 + env_ids) * 1048583 + self.epoch * 4096 + a * 64
+                w_for = lambda kk, base=base, m=ag.minibatch: minibatch_weights(self.complete_len, T, m, base + kk, n_total).reshape(-1)
             out[a] = ag.update_agent(actor_in, critic_in, buf.act[:, :, a].reshape(-1), adv, buf.ret[:, :, a].reshape(-1),
-                                     buf.logp[:, :, a].reshape(-1), w, update_critic=upd_c)
+                                     buf.logp[:, :, a].reshape(-1), w, update_critic=upd_c, w_for=w_for)
+        self.epoch += 1
         return out

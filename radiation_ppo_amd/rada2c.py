@@ -42,7 +42,8 @@ import torch.nn.functional as F
 from . import _lib
 from .envs import RadSearchVec
 from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
-from .ppo import DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, host_read, normalize_advantages, reduce_grads_and_stats
+from .ppo import (DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, check_minibatch, host_read, normalize_advantages,
+                  reduce_grads_and_stats, reject_unknown_kwargs)
 
 
 def _mlp_tanh(sizes) -> nn.Sequential:
@@ -494,13 +495,21 @@ class BpArgs:
 
 
 class RNNAgentPPO:
+    """AgentPPO, 'rnn' branch (ppo.py:601-683, :776-811).  `minibatch` (ppo.py:580) is validated and has no effect, as in the reference:
+    update_rada2c assigns it (ppo.py:1159-1160) and never reads it.  `train_v_iters` / `critic_learning_rate` have no counterpart
+    (RAD-A2C's value head is trained by the policy optimiser, ppo.py:1225, :1256-1258).  Any other unnamed key raises."""
+
+    _NO_EFFECT = ("train_v_iters", "critic_learning_rate")
+
     def __init__(self, id: int, observation_space: int = 11, action_space: int = 8, steps_per_epoch: int = 480,
                  steps_per_episode: int = 120, number_of_agents: int = 1, actor_critic_architecture: str = "rnn",
                  actor_critic_args: Optional[Dict[str, Any]] = None, train_pi_iters: int = 40, train_pfgru_iters: int = 15,
                  actor_learning_rate: float = 3e-4, pfgru_learning_rate: float = 5e-3, gamma: float = 0.99, alpha: float = 0.1,
                  clip_ratio: float = 0.2, target_kl: float = 0.07, lam: float = 0.9, bp_args: Optional[Any] = None,
                  env_height: float = 2500.0, seed: int = 0, device="cuda:0", episode_chunk: int = 32768,
-                 GlobalCriticOptimizer=None, **unused: Any):
+                 GlobalCriticOptimizer=None, minibatch: int = 1, **other: Any):
+        reject_unknown_kwargs("RNNAgentPPO", other, self._NO_EFFECT)
+        self.minibatch = check_minibatch(minibatch)
         # episode_chunk: episodes per pass of the update kernels.  One chunk for a whole 4096-env epoch (~16.5 k episodes): the recurrent
         # kernels (K12: one episode per lane) and the K11 passes are latency bound per launch, so three 8192-episode chunks cost three times
         # one 16 k chunk (RAD-A2C bench: 895 -> 972 k env steps/s).  K13's scratch grows with it: 1.8 MB per full-length episode (gates,
@@ -517,6 +526,8 @@ class RNNAgentPPO:
         self.bp_args = BpArgs(*(b if isinstance(b, tuple) else (b.bp_decay, b.l2_weight, b.l1_weight, b.elbo_weight, b.area_scale)))
         self.env_height, self.seed, self.episode_chunk = float(env_height), int(seed), int(episode_chunk)
         self.scratch = Scratch()
+        self.k13_particle_steps: List[int] = []          # particle-steps of each K13 launch of the current update_model (bench roofline)
+        self.k11_particle_steps: List[int] = []          # the same for the K11 passes (rs_pfgru_pass) of the current update_agent
         args = dict(actor_critic_args or {})
         args.setdefault("obs_dim", observation_space); args.setdefault("act_dim", action_space)
         self.agent = RNNModelActorCritic(**args).to(self.device)
@@ -600,6 +611,7 @@ class RNNAgentPPO:
         # ~120 ctypes calls per pass made it host-bound on a busy box (46 ms per policy iteration against 14 ms of kernels)
         Xc = X.contiguous()
         alive_h = (C.c_int32 * L)(*alive)
+        self.k11_particle_steps.append(40 * (int(sum(lens_host)) if lens_host is not None else L * E))
         with _lib.timed("rs_pfgru_pass"):
             _lib.check(lib.rs_pfgru_pass(wts.data_ptr(), Xc.data_ptr(), h.data_ptr(), p.data_ptr(), base.data_ptr(), episode.data_ptr(), calls.data_ptr(),
                                          float(self.agent.model.resamp_alpha), loc.data_ptr(), alive_h, L, E, st), "rs_pfgru_pass")
@@ -664,23 +676,26 @@ class RNNAgentPPO:
             tt = torch.arange(L, device=dev, dtype=torch.float64).unsqueeze(1)
             bp = torch.exp(a.bp_decay * tt) * Bc.valid.double()
             bp = (bp / bp.sum(dim=0, keepdim=True)).float().contiguous()           # :1074-1075
-            sc, tag = self.scratch, f"_{sl.start}"
-            idx0 = sc.get("k13_idx" + tag, (L, E, 40), torch.int32, dev)
-            idx0.zero_()                                                           # idx: steps beyond an episode's end are never written
             cache[ck] = (X, (Bc.src / a.area_scale).float().contiguous(), bp, Bc.lens.contiguous(), Bc.w_ep.float().contiguous(),
-                         sc.get("k13_hs" + tag, (L, E, 40, 24), torch.float32, dev), sc.get("k13_ps" + tag, (L, E, 40), torch.float32, dev), idx0)
-        X, tar, bp, lens, w_ep, hs, ps, idx = cache[ck]
+                         int(sum(Bc.lens_host)) * 40)
+        X, tar, bp, lens, w_ep, particle_steps = cache[ck]
         L, E = X.shape[0], X.shape[1]
+        # the walk's scratch (particle sets, log weights, indices, gates: 2.4 MB per full-length episode) is ONE set of buffers shared by
+        # all chunks and iterations -- launches are stream ordered, and a chunk's pass is done with them when the next one starts
+        sc = self.scratch
+        hs = sc.get("k13_hs", (L, E, 40, 24), torch.float32, dev)
+        ps = sc.get("k13_ps", (L, E, 40), torch.float32, dev)
+        idx = sc.get("k13_idx", (L, E, 40), torch.int32, dev)
+        gates = sc.get("k13_gates", (L * E * 40 * 96,), torch.float32, dev)         # the forward walk's gates: 384 B per particle-step
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         slab = torch.empty(E, PF_TRAIN_GRAD_FLOATS, dtype=torch.float32, device=dev)
         w = pack_train_weights(self.agent.model)
-        # for the bench's roofline entry: one count per launch, in launch order (as _lib.EVENTS["rs_pfgru_train"])
-        self.k13_particle_steps = getattr(self, "k13_particle_steps", [])
-        self.k13_particle_steps.append(int(sum(B.chunk(sl).lens_host)) * 40)
+        # for the bench's roofline entry: one count per launch of the current update_model, in launch order (as _lib.EVENTS["rs_pfgru_train"])
+        self.k13_particle_steps.append(particle_steps)
         if d._u is None:                                                           # recorded draws: idx is the kernel's INPUT
             idx.copy_(d._idx32)
-        # the forward walk's gates (384 B per particle-step): one scratch buffer shared by all chunks and iterations (stream ordered)
-        gates = self.scratch.get("k13_gates", (L * E * 40 * 96,), torch.float32, dev)
+        else:
+            idx.zero_()                                                            # steps beyond an episode's end are never written
         with _lib.timed("rs_pfgru_train"):
             _lib.check(_lib.load().rs_pfgru_train(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
                                                   d._pf.data_ptr(), d._eps.data_ptr(), None if d._u is None else d._u.data_ptr(), hs.data_ptr(), ps.data_ptr(),
@@ -689,21 +704,42 @@ class RNNAgentPPO:
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
         return loss.double().sum(), slab.sum(dim=0), idx
 
+    # K13's scratch per episode of L steps, bytes: gates 40 x 96, particle sets + noise 2 x 40 x 24 floats, resampling uniforms 40 doubles,
+    # log weights + indices 2 x 40 words per step (+ Scratch's 1/8 headroom)
+    _K13_BYTES_PER_EPISODE_STEP = (40 * 96 + 2 * 40 * 24) * 4 + 40 * 8 + 2 * 40 * 4
+
+    def _k13_chunk(self, L: int, E: int) -> int:
+        """Episodes per K13 pass: `episode_chunk`, clamped so that the pass's scratch fits the memory that is free NOW (plus what the
+        scratch already holds) -- a part with less HBM than an MI355X, or more envs, gets more passes instead of an out-of-memory
+        error in the middle of the first update."""
+        chunk = min(self.episode_chunk, max(E, 1))
+        if self.device.type != "cuda":
+            return chunk
+        held = sum(b.numel() * b.element_size() for k, b in self.scratch.bufs.items() if k[0].startswith(("k13_", "draws_")))
+        free = torch.cuda.mem_get_info(self.device)[0] + held
+        per_ep = L * self._K13_BYTES_PER_EPISODE_STEP * 9 // 8
+        fit = int(0.85 * free) // max(per_ep, 1)
+        if fit < 1:
+            raise MemoryError(f"K13 needs {per_ep / 1e6:.1f} MB of scratch per episode; {free / 1e9:.2f} GB are free")
+        return min(chunk, fit)
+
     def update_model(self, B: EpisodeBatch, draws_for=None) -> float:
         """update_model (ppo.py:1047-1148).  draws_for(iteration, slice) -> draws; default: counter hashes."""
         cell = self.agent.model
         cell.train()
         E = B.lens.shape[0]
         last = 0.0
+        self.k13_particle_steps = []                                               # this update's launches only
+        chunk = self._k13_chunk(B.X.shape[0], E)
         for it in range(self.train_pfgru_iters):
             self.model_optimizer.zero_grad(set_to_none=True)
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
-            for lo in range(0, E, self.episode_chunk):
-                sl = slice(lo, min(lo + self.episode_chunk, E))
+            for lo in range(0, E, chunk):
+                sl = slice(lo, min(lo + chunk, E))
                 if draws_for is not None:
                     d = draws_for(it, sl)
                 elif self.device.type == "cuda" and self.agent.fused_pfgru:
-                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0], scratch=self.scratch, tag=f"_{lo}")
+                    d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0], scratch=self.scratch)
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it, H=self.agent.rec, hid=self.agent.hid)
                 if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
@@ -828,6 +864,7 @@ class RNNAgentPPO:
     def update_agent(self, B: EpisodeBatch) -> UpdateResult:
         """update_agent, 'rnn' branch (ppo.py:776-811)."""
         self.agent.train()
+        self.k11_particle_steps = []
         model_loss = self.update_model(B)
         self.pi_optimizer.zero_grad(set_to_none=True)
         kk, term, s = 0, False, None

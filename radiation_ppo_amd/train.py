@@ -76,6 +76,13 @@ class train_PPO:
             self.parent_logger = EpochLogger(**pk)
             self.parent_logger.save_config(cfg)
         self.loggers = {}
+        # where rank 0's first agent writes: every rank leaves its own env / collector state there (save_resume)
+        self._dir0 = None
+        if "data_dir" in kw:
+            self._dir0 = setup_logger_kwargs(exp_name=f"0_agent_{kw.get('exp_name', '')}", seed=kw.get("seed"), data_dir=kw["data_dir"],
+                                             env_name=kw.get("env_name"))["output_dir"]
+        elif kw.get("output_dir"):
+            self._dir0 = os.path.join(str(kw["output_dir"]), "0_agent")
         for i in range(self.number_of_agents):
             if write and "data_dir" in kw:
                 lk = setup_logger_kwargs(exp_name=f"{i}_agent_{kw.get('exp_name', '')}", seed=kw.get("seed"),
@@ -117,6 +124,7 @@ class train_PPO:
                 gc = CNNCritic(map_dim=kw["map_dim"]).to(self.vec.device)
                 gco = torch.optim.Adam(gc.parameters(), lr=kw.get("critic_learning_rate", 1e-3))
             kw.pop("GlobalCriticOptimizer", None)
+            kw.setdefault("seed", self.seed)                                   # keys the minibatch draws (ppo.py:754-766)
             self.collector = None
             self.agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, device=self.vec.device, **kw)
                            for i in range(self.number_of_agents)}
@@ -161,22 +169,28 @@ class train_PPO:
                 self.loggers[i].save_state({}, None)
 
     def save_resume(self) -> None:
-        """After the update of the same epochs: <agent dir>/resume.pt = weights + optimiser moments + step counts + LR-schedule
-        position + the epoch counter (what the reference lacks for a true resume)."""
+        """After the update of the same epochs (called on EVERY rank).  Rank 0: <agent dir>/resume.pt = weights + optimiser moments +
+        step counts + LR-schedule position + the epoch counter (what the reference lacks for a true resume) -- the
+        rank-identical part.  Every rank: <first agent dir>/resume_rank<r>.pt = ITS env workspace (positions, sources, rectangles,
+        Philox counters of its own env ids), its collector's running episode state (Welford / heat maps / particle sets / GRU states,
+        episode and epoch counters that key the draws) and its host generator: a rank that continued from rank 0's state would repeat
+        rank 0's envs under its own draw keys."""
         for i, ag in self.agents.items():
             d = self.loggers[i].output_dir
             if d:
-                st = dict(agent=ag.resume_state(), epochs_done=self.epochs_done, torch_rng=torch.get_rng_state())
-                if i == min(self.agents):
-                    # the env and the collector's running episode state (Philox counters, Welford / heat-map / particle state,
-                    # episode and epoch counters that key the draws): with them a resumed run IS the uninterrupted one
-                    st["collector"] = self.collector.resume_state()
-                torch.save(st, os.path.join(d, "resume.pt"))
+                torch.save(dict(agent=ag.resume_state(), epochs_done=self.epochs_done, world_size=self.world), os.path.join(d, "resume.pt"))
+        if self._dir0:
+            os.makedirs(self._dir0, exist_ok=True)
+            torch.save(dict(collector=self.collector.resume_state(), torch_rng=torch.get_rng_state(), world_size=self.world,
+                            epochs_done=self.epochs_done), os.path.join(self._dir0, f"resume_rank{self.rank}.pt"))
 
     def load(self, directory: str) -> None:
         """Resume from agent directories `<directory>/<id>_agent...` written by save_resume(): weights, optimiser moments, step
-        counts, LR-schedule position, and -- from the first agent's file -- the env state, the collector's running episode state
-        and the host generator, so that the resumed run continues the saved one draw for draw (tests/test_train_logging_gpu.py)."""
+        counts, LR-schedule position from resume.pt, and -- from the first agent's resume_rank<r>.pt -- THIS rank's env state, collector
+        state and host generator, so that the resumed run continues the saved one draw for draw on every rank
+        (tests/test_train_logging_gpu.py; two ranks: tests/test_bench_dist_gpu.py).  Resuming with another world size raises: the
+        envs would be dealt differently and the run could not be the saved one."""
+        first_dir = None
         for i, ag in self.agents.items():
             cands = [os.path.join(directory, n) for n in sorted(os.listdir(directory)) if n.startswith(f"{i}_agent")]
             hits = ([c for c in cands if os.path.exists(os.path.join(c, "resume.pt"))]
@@ -186,11 +200,23 @@ class train_PPO:
                 raise FileNotFoundError(f"no resume.pt for agent {i} under {directory}")
             # tensors, containers and plain scalars only: the restricted loader suffices
             st = torch.load(os.path.join(hits[0], "resume.pt"), map_location=self.vec.device, weights_only=True)
+            if int(st.get("world_size", 1)) != self.world:
+                raise ValueError(f"resume.pt was written by {st.get('world_size', 1)} rank(s), this run has {self.world}")
             ag.load_resume_state(st["agent"])
             self.epochs_done = int(st["epochs_done"])
-            if "collector" in st:
+            first_dir = first_dir or hits[0]
+            if "collector" in st and self.world == 1:              # files of earlier versions: one rank, everything in resume.pt
                 self.collector.load_resume_state(st["collector"])
                 torch.set_rng_state(st["torch_rng"].cpu())
+        f = os.path.join(first_dir, f"resume_rank{self.rank}.pt")
+        if os.path.exists(f):
+            st = torch.load(f, map_location=self.vec.device, weights_only=True)
+            if int(st["world_size"]) != self.world or int(st["epochs_done"]) != self.epochs_done:
+                raise ValueError(f"{f} belongs to another run (world size {st['world_size']}, epoch {st['epochs_done']})")
+            self.collector.load_resume_state(st["collector"])
+            torch.set_rng_state(st["torch_rng"].cpu())
+        elif self.world > 1:
+            raise FileNotFoundError(f"{f}: every rank resumes from its own env / collector state")
 
     # ------------------------------------------------------------------ the loop
     def train(self) -> None:
@@ -201,8 +227,8 @@ class train_PPO:
         for epoch in range(self.epochs_done, self.total_epochs):
             t0 = time.time()
             stats = self.collector.collect()
-            saving = self.rank == 0 and ((epoch % self.save_freq == 0) or (epoch == self.total_epochs - 1))
-            if saving:
+            saving = (epoch % self.save_freq == 0) or (epoch == self.total_epochs - 1)
+            if saving and self.rank == 0:
                 self.save()                                                             # train.py:552-561 (before the update)
             if epoch > 99 and self.actor_critic_architecture == "rnn":                  # train.py:563-566
                 for ag in self.agents.values():

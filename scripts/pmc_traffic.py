@@ -62,6 +62,7 @@ if driver_log and os.path.exists(driver_log):
         lg = res["largest_grid_bytes_per_launch"]
         units = {"rs_cnn_fwd_kernel<6>": ("image", 32768), "rs_cnn_bwd_kernel<6>": ("image", 32768), "rs_cnn_fwd_kernel<4>": ("image", 32768),
                  "rs_cnn_bwd_kernel<4>": ("image", 32768), "rs_pfgru_kernel<false>": ("(owner, env) step", 4096 * 4),
+                 "rs_pfgru_kernel<false, 1>": ("(owner, env) step", 4096 * 4), "rs_pfgru_kernel<false, 4>": ("(episode, step)", 16384 * 4),
                  "rs_pfgru_train_kernel": ("particle-step", info["k13_particle_steps"]),
                  "rs_rollout16_kernel<true>": ("env-step", 8192 * 480), "rs_step4_kernel": ("env-step", 8192)}
         alg = info["algorithmic_bytes_per_launch"]
@@ -75,6 +76,10 @@ if driver_log and os.path.exists(driver_log):
         for k, (unit, n) in units.items():
             if k in lg:
                 a = alg.get(k, alg.get(k.split("<")[0]))
+                if k == "rs_pfgru_kernel<false, 4>":
+                    # its largest grid must be the full-size pass of the driver (2 731 workgroups of 256 threads), not a launch of the
+                    # 1024-env update further down
+                    assert lg[k]["grid"] == ((16384 + 5) // 6) * 256, lg[k]
                 res["per_unit"][k] = {"unit": unit, "units_per_launch": n, "hbm_bytes_per_unit": lg[k]["hbm_bytes_per_launch"] / n,
                                       "algorithmic_bytes_per_unit": (a / n) if a else None,
                                       "traffic_over_algorithmic": (lg[k]["hbm_bytes_per_launch"] / a) if a else None}

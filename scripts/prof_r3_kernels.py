@@ -66,6 +66,19 @@ torch.cuda.synchronize()
 alg["rs_pfgru_kernel"] = N * A * (2 * (40 * 24 * 4 + 40 * 4) + 12 + 8)        # particle set read + written back, obs row, prediction
 del b
 
+# ---- K11 as the policy loop runs it (round 4): one PASS over 16 384 full-length episodes = reset + 30 launches of four time steps
+# (rs_pfgru_kernel<false, 4>), the particle sets in registers between the steps of a launch
+from radiation_ppo_amd.rada2c import HashDraws
+E, Lp = 16384, 120
+agp = RNNAgentPPO(id=0, seed=2)
+Xp = torch.rand(Lp, E, 11, device="cuda")
+for _ in range(2):
+    agp._pfgru_pass_hip(Xp, HashDraws(torch.arange(E, device="cuda", dtype=torch.int64) * 64 + 17))
+torch.cuda.synchronize()
+# per launch: every set read and written back once (2 x 4 000 B), four observation rows (12 B used) and four predictions (8 B)
+alg["rs_pfgru_kernel<false, 4>"] = E * (2 * (40 * 24 * 4 + 40 * 4) + 4 * (12 + 8))
+del agp, Xp
+
 # ---- rollout16<true>, step4 (config 3)
 N, T, L = 8192, 480, 120
 env = RadSearchVec(N, obstruction_count=-1, enforce_grid_boundaries=True, seed=SEED)
@@ -90,7 +103,7 @@ col.buf.__init__(60, N, 1, 11, env.device)
 col.collect()
 col.update()
 torch.cuda.synchronize()
-ps = ag[0].k13_particle_steps[-1]
+ps = ag[0].k13_particle_steps[-1]                  # (one chunk: every K13 launch of the update covers the whole epoch)
 # per particle-step: forward reads eps 96 B, writes the resampled particle 96 + 4 + 4 B and the gates 384 B; backward reads the gates 384 B,
 # two particle sets 200 B and the index 4 B
 alg["rs_pfgru_train_kernel"] = ps * (96 + 104 + 384 + 384 + 2 * 100 + 4)

@@ -16,6 +16,54 @@ if world > 1:
 from radiation_ppo_amd.envs import RadSearchVec                      # noqa: E402
 from radiation_ppo_amd.ppo import Collectives, FusedCollector, VecAgentPPO        # noqa: E402
 
+if mode.startswith("resume"):
+    # a data-parallel run resumed from per-rank files (train_PPO.save_resume / load): 3 epochs in one go against 2 epochs + a fresh set
+    # of objects + load + 1 epoch, on every rank; `out` is a directory, rank 0 writes <out>/result.pt
+    from radiation_ppo_amd.train import train_PPO                    # noqa: E402
+    arch = mode.split("-")[1]
+    A = 2 if arch == "cnn" else 1
+    N = total_envs // world
+    kw = dict(seed=7, number_of_agents=A, actor_critic_architecture=arch, global_critic_flag=(arch == "cnn"), steps_per_epoch=20,
+              steps_per_episode=8, save_freq=1, ppo_kwargs=dict(train_pi_iters=2, train_v_iters=2, train_pfgru_iters=2, alpha=0.1))
+
+    def make(name, epochs):
+        env = RadSearchVec(N, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=11, env_id_base=rank * N)
+        return train_PPO(env=env, logger_kwargs=dict(output_dir=os.path.join(out, name)), total_epochs=epochs, **kw)
+
+    def params(sim):
+        mods = []
+        for ag in sim.agents.values():
+            mods += [ag.pi, ag.critic, ag.model] if arch == "cnn" else [ag.agent]
+        return torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()])
+
+    whole = make("whole", 3)
+    whole.train()
+    first = make("first", 2)
+    first.train()
+    if world > 1:
+        dist.barrier()                                               # every rank's resume_rank<r>.pt is on disk
+    second = make("second", 3)
+    second.load(os.path.join(out, "first"))
+    second.train()
+    same = all(torch.equal(getattr(whole.collector.buf, k), getattr(second.collector.buf, k))
+               for k in ("obs", "act", "rew", "val", "logp", "cut", "adv", "ret")) and torch.equal(params(whole), params(second))
+    # the shards must not be copies of each other (what loading rank 0's env state on every rank produced)
+    head = whole.collector.buf.obs[:, 0].reshape(-1)[:64].clone()
+    flag = torch.tensor([1.0 if same else 0.0], device="cuda")
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        heads = [torch.empty_like(head) for _ in range(world)]
+        dist.all_gather(heads, head)
+        distinct = not torch.equal(heads[0], heads[1])
+    else:
+        distinct = True
+    if rank == 0:
+        torch.save({"equal": bool(flag.item() == 1.0), "distinct_shards": distinct, "epochs": second.epochs_done,
+                    "files": sorted(os.listdir(os.path.join(out, "first", "0_agent")))}, os.path.join(out, "result.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0)
 if mode == "cnn":
     # BASELINE config 5 in miniature: multi-agent RAD-TEAM (CNN actors, global critic, obstacles) sharded over ranks
     from radiation_ppo_amd.maps import CNNCritic                      # noqa: E402

@@ -16,7 +16,8 @@ def _dense_actor_stack(maps, cells, pcells, a):
     """CNNBase.get_map_stack (RADTEAM_core.py:1791-1836) written with torch ops."""
     B = maps.shape[0]
     loc = torch.zeros(B, 729, device=maps.device)
-    loc.scatter_(1, cells[:, a:a + 1], 1.0)
+    c = cells[:, a:a + 1]
+    loc.scatter_(1, c.clamp(min=0), (c >= 0).float())     # -1: no position recorded yet (fresh maps) -> an empty location map
     pm = torch.zeros(B, 729, device=maps.device)
     pc = pcells[:, a:a + 1]
     pm.scatter_(1, pc.clamp(min=0), (pc >= 0).float())
@@ -35,6 +36,8 @@ def _random_inputs(S, A, seed):
     maps[:, 0].view(S, 729).scatter_add_(1, cells, torch.ones(S, A, device="cuda"))   # every owner stands somewhere
     # corners and edges exercise the zero padding and the dropped 27th row/column
     cells[0, 0], cells[1 % S, 0], cells[2 % S, 0] = 0, 728, 26
+    if S > 4:
+        cells[3, 0] = -1                                  # a fresh map without a recorded position (maps.actor_stack_from: empty one-hot)
     return maps.contiguous(), cells.contiguous(), pcells.contiguous()
 
 

@@ -138,3 +138,61 @@ def test_evaluate_ppo_driver_with_the_recurrent_agent(tmp_path):
                            steps_per_episode=10, enforce_boundaries=True, seed=1))
     results, summary = ev.evaluate()
     assert len(results) == 3 and summary["completed_runs"] == 12 and 0.0 <= summary["success_rate"] <= 1.0
+
+
+def test_sequential_runs_carry_the_hidden_state_like_the_reference(monkeypatch):
+    """carry_hidden_across_runs=True (evaluate.py:357, :455-470): the runs of one saved environment follow each other on one lane;
+    `hiddens` is created once, the statistics buffer restarts with every run.  (i) With one run per environment the sequential form IS
+    the lane-per-run form (same lanes, same Philox streams): identical records.  (ii) With several runs every lane replays through the
+    oracle -- refresh_environment, the logged actions, refresh again ... -- to the same lengths / success flags / returns in run order,
+    while the GRU's h0 and the particle sets were drawn exactly once and the Welford state restarted once per run."""
+    from radiation_ppo_amd import evaluate as ev
+    from radiation_ppo_amd.pfgru import PredictorBank
+    from radiation_ppo_amd.ppo import DeviceWelford
+    from radiation_ppo_amd.rada2c import RNNAgentPPO
+    torch.manual_seed(9)
+    E, L, seed, obst = 6, 30, 123, 2
+    sets = ev.sample_test_environments(E, obstruction_count=obst, seed=77)
+    agent = RNNAgentPPO(id=0, steps_per_episode=L)
+    with torch.no_grad():
+        for p in agent.agent.pi.parameters():
+            p.mul_(4.0)
+    a1, s1 = ev.run_test_environments(agent, sets, montecarlo_runs=1, steps_per_episode=L, obstruction_count=obst, seed=seed)
+    b1, t1 = ev.run_test_environments(agent, sets, montecarlo_runs=1, steps_per_episode=L, obstruction_count=obst, seed=seed,
+                                      carry_hidden_across_runs=True)
+    assert [r.total_episode_length for r in a1] == [r.total_episode_length for r in b1]
+    assert [r.success_counter for r in a1] == [r.success_counter for r in b1] and s1["success_rate"] == t1["success_rate"]
+    assert [r.successful.episode_return + r.unsuccessful.episode_return for r in a1] == [r.successful.episode_return + r.unsuccessful.episode_return for r in b1]
+
+    calls = {"h0": 0, "bank_reset": 0, "stat_reset": 0}
+    h0, br, sr = agent.agent.gru_h0, PredictorBank.reset, DeviceWelford.reset
+    monkeypatch.setattr(agent.agent, "gru_h0", lambda u: (calls.__setitem__("h0", calls["h0"] + 1), h0(u))[1])
+    monkeypatch.setattr(PredictorBank, "reset", lambda self, mask=None: (calls.__setitem__("bank_reset", calls["bank_reset"] + 1), br(self, mask))[1])
+    monkeypatch.setattr(DeviceWelford, "reset", lambda self, mask: (calls.__setitem__("stat_reset", calls["stat_reset"] + 1), sr(self, mask))[1])
+    R = 4
+    results, summary, actions = ev.run_test_environments(agent, sets, montecarlo_runs=R, steps_per_episode=L, obstruction_count=obst, seed=seed,
+                                                         carry_hidden_across_runs=True, return_actions=True)
+    assert calls["h0"] == 1 and calls["bank_reset"] == 1 and calls["stat_reset"] == actions.shape[0]
+    assert summary["completed_runs"] == E * R
+    for e, res in enumerate(results):
+        s = sets[f"env_{e}"]
+        rects = [(int(o[0][:, 0].min()), int(o[0][:, 1].min()), int(o[0][:, 0].max()), int(o[0][:, 1].max())) for o in s[4]]
+        ref = RadSearchOracle(PhiloxDraws(seed, e), number_agents=1, obstruction_count=obst, enforce_grid_boundaries=True)
+        ref.refresh_environment(s[0], s[1], s[2], s[3], rects)
+        lens, rets, sucs = [], [], []
+        ret, steps = np.float32(0.0), 0
+        for t in range(actions.shape[0]):
+            if actions[t, e] < 0:
+                break
+            o, rew, done, _ = ref.step({0: int(actions[t, e])})
+            ret = np.float32(ret + np.float32(rew["individual_reward"][0]))
+            steps += 1
+            if done[0] or steps == L:
+                lens.append(steps); rets.append(float(ret)); sucs.append(bool(done[0]))
+                ret, steps = np.float32(0.0), 0
+                ref.refresh_environment(s[0], s[1], s[2], s[3], rects)
+        assert len(lens) == R and res.total_episode_length == lens, (e, lens, res.total_episode_length)
+        assert res.success_counter == sum(sucs)
+        assert res.successful.episode_length == [l for l, k in zip(lens, sucs) if k]
+        assert np.allclose(res.successful.episode_return, [r for r, k in zip(rets, sucs) if k], atol=1e-4)
+        assert np.allclose(res.unsuccessful.episode_return, [r for r, k in zip(rets, sucs) if not k], atol=1e-4)

@@ -423,3 +423,85 @@ def test_actor_loss_kernel_equals_the_torch_composition():
     assert 0.1 < float(want[2]) < 0.9
     assert torch.allclose(st, want, rtol=2e-5, atol=1e-8), (st, want)
     assert torch.allclose(gk, logits.grad, rtol=1e-4, atol=1e-6 * float(logits.grad.abs().max())), float((gk - logits.grad).abs().max())
+
+
+def test_cnn_update_draws_the_reference_s_minibatch_sample():
+    """`minibatch` on the 'cnn' path (ppo.py:754-766, :825-873): every actor iteration works on int(ep_len / minibatch) drawn indexes per
+    env, the critic loop on the LAST draw.  With learning rates 0 the logged actor loss of an update with minibatch = 3 must equal
+    the weighted mean over exactly the drawn subset of the last iteration, computed here from the dense library-convolution path;
+    minibatch = 1 must reproduce the update without the option bit for bit."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo import normalize_advantages
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector, minibatch_weights
+    N, A, T, L = 16, 2, 30, 9
+
+    def run(minibatch):
+        torch.manual_seed(2)
+        env = RadSearchVec(N, number_agents=A, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED)
+        gc = CNNCritic().cuda()
+        gco = torch.optim.Adam(gc.parameters(), lr=0.0)
+        kw = {} if minibatch is None else dict(minibatch=minibatch)
+        agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=gco, train_pi_iters=3, train_v_iters=2, actor_learning_rate=0.0,
+                                 target_kl=1e9, seed=7, **kw) for i in range(A)}
+        col = CNNCollector(env, agents, T, L, global_critic_flag=True)
+        col.collect()
+        return col, agents, col.update()
+
+    col0, _, r0 = run(None)
+    col1, _, r1 = run(1)
+    assert r0[0].loss_policy == r1[0].loss_policy and r0[0].loss_critic == r1[0].loss_critic and r0[1].kl_divergence == r1[1].kl_divergence
+    col, agents, r3 = run(3)
+    assert col.epoch == 1
+    buf = col.buf
+    ids = torch.arange(N, device="cuda", dtype=torch.int64)
+    for a in range(A):
+        base = (7 * 4294967296 + ids) * 1048583 + 0 * 4096 + a * 64
+        w = minibatch_weights(col.complete_len, T, 3, base + 2, N)                     # the draw of the last (third) iteration
+        assert torch.equal((w > 0).sum(0), col.complete_len // 3)
+        stack = col.actor_stack_from(col.shared.view(T * N, 4, 27, 27), col.cells.view(T * N, A), col.pcells.view(T * N, A), a)
+        with torch.no_grad():
+            logp_all = torch.log_softmax(agents[a].pi.logits(stack), dim=-1)
+        logp = logp_all.gather(-1, buf.act[:, :, a].reshape(-1, 1)).squeeze(-1)
+        adv = normalize_advantages(buf.adv[:, :, a]).reshape(-1)
+        ratio = torch.exp(logp - buf.logp[:, :, a].reshape(-1))
+        want = -(w.reshape(-1) * torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv)).sum()
+        assert abs(r3[a].loss_policy - float(want)) < 1e-5 * max(1.0, abs(float(want))), (a, r3[a].loss_policy, float(want))
+    assert r3[0].loss_policy != r0[0].loss_policy
+    with pytest.raises(ValueError, match="minibatch"):
+        c2, ag2, _ = run(1)
+        for g in ag2.values():
+            g.minibatch = 10_000
+        c2.collect(); c2.update()
+
+
+def test_heat_maps_bin_the_noisy_coordinates_when_coord_noise_is_on():
+    """coord_noise=True (rad_search_env.py:365, :569-580): the reference's MapsBuffer bins the OBSERVED coordinates
+    (int(observation[1] * resolution_accuracy), RADTEAM_core.py:705-711), which carry N(0, 5 cm), not the exact position.  K5 fed by the
+    noisy env must equal the MapsBuffer oracle fed the same observation rows, float32-exact, and some step must land in another cell than
+    the exact position would (otherwise the test would not see the difference)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import HeatMaps
+    N, L, A = 48, 14, 2
+    env = RadSearchVec(N, number_agents=A, obstruction_count=0, enforce_grid_boundaries=True, seed=SEED, coord_noise=True)
+    hm = HeatMaps(env, steps_per_episode=L)
+    bufs = [[MapsOracle(steps_per_episode=L, number_of_agents=A) for _ in range(A)] for _ in range(N)]
+    obs_t = env.reset()[0]
+    rng = np.random.default_rng(5)
+    moved = 0
+    for t in range(12):
+        pred = torch.rand(N, A, 2, generator=torch.Generator().manual_seed(t)).cuda()
+        hm.update(obs_t, pred)
+        actor = hm.stacks()[0].cpu().numpy()
+        o, pc = obs_t.double().cpu().numpy(), pred.cpu().numpy()
+        x, y = env.state("x").cpu().numpy(), env.state("y").cpu().numpy()
+        for n in range(N):
+            od = {i: o[n, i] for i in range(A)}
+            for i in range(A):
+                m = bufs[n][i].observation_to_map(od, i, (float(pc[n, i, 0]), float(pc[n, i, 1])))
+                assert np.array_equal(actor[n, i], np.stack([m[0], m[1], m[2], m[3], m[4], m[5]])), (t, n, i)
+                exact = (int(x[i, n] / 2200.0 * 22.0), int(y[i, n] / 2200.0 * 22.0))
+                moved += int((int(o[n, i, 1] * 22.0), int(o[n, i, 2] * 22.0)) != exact)
+        acts = rng.integers(0, 8, size=(N, A)).astype(np.int8)
+        obs_t = env.step(torch.from_numpy(acts).cuda())[0]
+    assert moved > 0 and int(hm.field("err").max().item()) == 0
