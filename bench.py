@@ -330,6 +330,10 @@ def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     del env64
     tr_roll, src_roll = unit_traffic("rs_rollout16_kernel<true>")
     tr_step, src_step = unit_traffic("rs_step4_kernel")
+    # the obstacle step also reads the env's rectangles (16 B each) and the cached geodesics source -> rectangle vertex (4 x 8 B each):
+    # SURVEY section 8d "+ 16 O B rectangle reads + 4 4 O B cached distances" (float64 here: 32 O)
+    mean_obs = float(env.state("num_obs").float().mean().item())
+    step4_bytes = K1_BYTES_PER_AGENT_STEP + (16 + 32) * mean_obs
     out = {"workload": "single-agent RadSearch, 1 source + U{1..5} random rectangles per env, 8192 envs, 2x64 MLP, 480 steps/epoch",
            "envs": N, "steps": iters, "warmup": warmup, "value": iters * N * T / dt, "unit": "env steps/s",
            "ms_per_step": 1e3 * dt / iters, "phase_ms": {"collect": 1e3 * tc / iters, "update": 1e3 * tu / iters},
@@ -346,11 +350,12 @@ def run_config3(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
                                  "avg_launch_ms_shared_geometry_64": k1s["avg_ms"],
                                  "env_only_steps_per_s": N / (k1["avg_ms"] * 1e-3),
                                  "env_only_steps_per_s_shared_geometry_64": N / (k1s["avg_ms"] * 1e-3),
-                                 "achieved": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": K1_BYTES_PER_AGENT_STEP * N / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "achieved": step4_bytes * N / (k1["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": step4_bytes * N / (k1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None if tr_step is None else tr_step * N, "traffic_source": src_step,
-                                 "bytes_per_launch": K1_BYTES_PER_AGENT_STEP * N,
-                                 "note": "157 B/agent-step counted (obstacle rectangles 16 B x O and cached geodesics 32 B x O per env not counted)"},
+                                 "bytes_per_launch": step4_bytes * N, "mean_rectangles_per_env": mean_obs,
+                                 "note": f"{step4_bytes:.0f} B per env-step = 157 B state / outputs + (16 B rectangle + 32 B cached geodesics) x "
+                                         f"{mean_obs:.2f} rectangles per env; latency bound (the serial exact-geometry chain of the slowest env of a wave)"},
            "gae_ms": gae_ms}
     flags = env.error_flags()
     out["env_error_flags"] = flags

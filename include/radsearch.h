@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 2
+#define RS_ABI_VERSION 3
 #define RS_OBS_DIM 11      /* [measurement, x/scale, y/scale, 8 range sensors]  rad_search_env.py:589-593 */
 #define RS_NUM_ACTIONS 9   /* 0..7 directions, 8 idle                           rad_search_env.py:55-68  */
 #define RS_MAX_AGENTS 8
@@ -401,6 +401,11 @@ int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const
 #define RS_RNN_POLICY_WEIGHT_FLOATS 5296
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
+/* The same step reading agent a's rows straight out of the collectors' [N][A][.] tensors (x_stride / loc_stride / u_stride: floats
+ * between consecutive envs' rows) and writing the action once more as int8 into rs_step's action row (act8 [N][act8_stride]). */
+int rs_rnn_policy_step_rows(const float* weights, const float* x, int32_t x_stride, const float* loc, int32_t loc_stride, const float* h,
+                            const float* u, int32_t u_stride, float* h_out, float* value, int64_t* act, float* logp, int8_t* act8,
+                            int32_t act8_stride, int32_t num_envs, rs_stream_t stream);
 
 /* The heads of the RAD-A2C actor-critic, update_rada2c's per-sample loss (algos/multiagent/ppo.py:1191-1234: PPO-clip surrogate on
  * the policy head, vf_coef x squared error on the value head; the entropy term carries no gradient) and their back-propagation,
@@ -457,6 +462,40 @@ int rs_store_rows(const int64_t* t, const int64_t* act, const float* logp_val_bo
                   const float* rew, const uint8_t* cut, const uint8_t* boot, int64_t* buf_act, float* buf_logp, float* buf_val,
                   float* buf_last_val, float* buf_obs, float* buf_source, float* buf_rew, uint8_t* buf_cut, int32_t num_envs,
                   int32_t num_agents, int32_t steps_per_epoch, rs_stream_t stream);
+
+/* The element-wise bookkeeping of one collector lock-step between the library calls -- the epoch loop body of train_PPO.train
+ * (algos/multiagent/train.py:332-548) for all envs at once: what the reference does in Python per env and step, as three launches.
+ * Every pointer is a device buffer of the caller (addresses fixed for the life of the collector: the lock-step is replayed as a graph).
+ *   rs_collect_pre        x <- obs with the reading (column 0) standardised by the running statistics (:334-341)
+ *   rs_collect_post_step  after rs_step: ep_ret += reward (the team reward for every agent when team_reward != 0, :366-375),
+ *                         steps_in_ep += 1, over = any agent's terminal flag | steps_in_ep == steps_per_episode (:387-405),
+ *                         cut = over (everything at the epoch's last step), boot = timeouts (all cut envs at the epoch's last step:
+ *                         the envs whose value is bootstrapped, :462-487); Welford update with the new readings (:432-436);
+ *                         obs <- env_obs; xb <- its standardised form; pf_calls += 1 (the predictor bank's per-env call counter)
+ *   rs_collect_post_reset after rs_reset(cut): pf_calls += boot (the bootstrap round's prediction); for the cut envs obs <- env_obs,
+ *                         ep_ret = 0, steps_in_ep = 0, statistics restarted on the first reading (:504-548) and, with reset_hidden,
+ *                         pf_episode += 1, pf_calls = 0, episodes_begun += 1 (the draw counters rs_pfgru_reset / rs_gru_h0_reset read);
+ *                         t += 1 */
+typedef struct {
+    int32_t num_envs, num_agents, steps_per_episode, team_reward;
+    const float* env_obs;         /* [N][A][11] the env's observation rows (output of rs_step / rs_reset) */
+    const float* env_reward;      /* [N][A] */
+    const float* env_team;        /* [N] */
+    const uint8_t* env_done;      /* [N][A] */
+    float* obs;                   /* [N][A][11] the collector's current observation */
+    float* ep_ret;                /* [N][A] */
+    int32_t* steps_in_ep;         /* [N] */
+    double* w_count; double* w_mean; double* w_sq; double* w_std;     /* [N][A] Welford state of the readings; all NULL: no standardisation */
+    float* x;                     /* [N][A][11] policy input of the step (rs_collect_pre); may be NULL for post_step / post_reset */
+    float* xb;                    /* [N][A][11] policy input of the bootstrap round, or NULL */
+    float* reward_used;           /* [N][A] or NULL */
+    uint8_t* over; uint8_t* cut; uint8_t* boot;                        /* [N] */
+    int64_t* pf_episode; int64_t* pf_calls; int64_t* episodes_begun;   /* [N] or NULL */
+    int64_t* t;                   /* [1] device-side step counter, or NULL */
+} rs_collect_state;
+int rs_collect_pre(const rs_collect_state* c, rs_stream_t stream);
+int rs_collect_post_step(const rs_collect_state* c, int32_t epoch_ended, rs_stream_t stream);
+int rs_collect_post_reset(const rs_collect_state* c, int32_t reset_hidden, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,13 @@ class RsConfig(C.Structure):
     ]
 
 
+class RsCollectState(C.Structure):
+    """rs_collect_state (include/radsearch.h)."""
+    _fields_ = [("num_envs", C.c_int32), ("num_agents", C.c_int32), ("steps_per_episode", C.c_int32), ("team_reward", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("env_obs", "env_reward", "env_team", "env_done", "obs", "ep_ret", "steps_in_ep", "w_count", "w_mean", "w_sq",
+                                  "w_std", "x", "xb", "reward_used", "over", "cut", "boot", "pf_episode", "pf_calls", "episodes_begun", "t")]
+
+
 class RsMlpParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
@@ -105,6 +112,11 @@ SYMBOLS = [
     ("rs_pfgru_draws", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rs_pfgru_train", C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("rs_rnn_policy_step", C.c_int, [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
+    ("rs_rnn_policy_step_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("rs_collect_pre", C.c_int, [C.POINTER(RsCollectState), C.c_void_p]),
+    ("rs_collect_post_step", C.c_int, [C.POINTER(RsCollectState), C.c_int32, C.c_void_p]),
+    ("rs_collect_post_reset", C.c_int, [C.POINTER(RsCollectState), C.c_int32, C.c_void_p]),
     ("rs_welford_update", C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_welford_reset", C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_welford_standardize", C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
@@ -158,7 +170,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rs_abi_version() != 2:
+    if lib.rs_abi_version() != 3:
         raise RuntimeError("librs_hip.so ABI version mismatch")
     _lib = lib
     return lib

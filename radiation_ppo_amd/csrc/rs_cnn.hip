@@ -24,6 +24,7 @@
 //     the caller reduces (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/radsearch.h"
 
@@ -60,11 +61,27 @@ constexpr int XP_RS = 28, XP_PLANE = 28 * 28 + 6;   // padded input plane: xp[r]
                                                 // border only feeds conv1 row/column 26, which the pool drops; even stride (b64 reads)
 constexpr int XP_PLANE_B = 28 * 28 + 7;         // backward: ODD plane stride -- the dW1 gather's two channel halves (2 planes apart) must
                                                 // land in the other 16 LDS banks (see the bank map in rs_cnn_bwd_kernel)
-constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane / padded dZ2 plane
+constexpr int PP_RS = 15, PP_PLANE = 15 * 15;   // padded pooled plane (forward)
+// Backward: K10 is LDS-bandwidth bound (profiles/r04_cnn_sq_counters.txt: the LDS pipe busy ~90 % of the time, more than half of it bank
+// conflicts), so the padded P1 / dZ2 planes get the strides that make the matrix-core operand reads conflict free -- row stride 18, plane
+// stride 278 (= 22 mod 32): the 16 taps x 2 pixels a half-wave reads as B operands fall into 32 different banks (2.8-way on average
+// with 15 / 225), the 16 channels x 2 pixels of the A operand too -- and dP1's pixel threads take their pixels from BWD_SLOT_PIXEL,
+// a table that gives every half-wave 28-29 pixels whose addresses 18 py + px are distinct mod 32 (with pixel = thread index two of
+// the three 13-pixel rows a half-wave touches overlap: every one of the 144 neighbourhood reads took two passes).
+constexpr int PPB_RS = 18, PPB_PLANE = 278;
+// slot (thread of the three pixel waves; pass k, lane of the helper wave) -> pixel, 255 = none; generated for row stride 18
+__device__ const unsigned char BWD_SLOT_PIXEL[192] = {
+    0, 1, 2, 4, 6, 8, 9, 10, 12, 15, 19, 21, 22, 23, 25, 36, 39, 59, 60, 74, 76, 89, 92, 107, 122, 135, 148, 154, 161, 255, 255, 255,
+    13, 16, 26, 28, 30, 31, 32, 34, 35, 41, 43, 44, 45, 47, 49, 50, 51, 58, 64, 81, 82, 88, 96, 98, 111, 141, 144, 157, 255, 255, 255, 255,
+    11, 24, 52, 53, 54, 56, 57, 62, 65, 66, 67, 69, 71, 72, 73, 75, 77, 80, 86, 87, 90, 104, 110, 118, 120, 133, 152, 163, 255, 255, 255, 255,
+    7, 14, 20, 33, 46, 61, 78, 79, 84, 91, 93, 94, 95, 97, 99, 101, 102, 103, 108, 109, 112, 114, 115, 116, 129, 132, 153, 167, 255, 255, 255, 255,
+    5, 18, 29, 42, 48, 55, 63, 68, 83, 106, 117, 119, 121, 123, 124, 125, 127, 128, 130, 131, 134, 136, 137, 138, 140, 142, 151, 165, 255, 255, 255, 255,
+    3, 17, 27, 37, 38, 40, 70, 85, 100, 105, 113, 126, 139, 143, 145, 146, 147, 149, 150, 155, 156, 158, 159, 160, 162, 164, 166, 168, 255, 255, 255, 255};
 constexpr int C1 = 8, C2 = 16, FLAT = C2 * PC;  // 2704
 constexpr int DP1_SPLIT = 13;                   // backward, dP1: output channels [0, 13) on the pixel threads, [13, 16) on the helper wave (measured: 16 -> 707, 13 -> 672, 12 -> 676, 10 -> 703 us per 32768 images)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 // Weights are read through the scalar unit: a wave-uniform s_load_dwordx8/x16 from the constant address space feeds
 // v_fma's SGPR operand, so they cost neither LDS return bandwidth nor VGPRs.  (Broadcast ds_reads still return
 // 64 x 16 B per wave and made conv2 / dP1 LDS-bound.)  The scalar loads want [tap][channel] rows, produced once per
@@ -103,6 +120,45 @@ __global__ void rs_cnn_prep_kernel(int cin, const float* __restrict__ w1, const 
     if (threadIdx.x < 16) wt[WT_B2(cin) + threadIdx.x] = b2 ? b2[threadIdx.x] : 0.0f;
 }
 
+// Weight rows through the scalar unit in the order  wait for this block -> request the next block -> this block's FMAs  (csrc/rs_sstream.hpp
+// explains why: scalar loads return out of order, s_waitcnt lgkmcnt(0) drains everything in flight, and hipcc on its own requests a
+// block and waits right behind it -- in K9 / K10 every tap group exposed a full scalar round trip, ~40 % of the SIMD time idle at
+// 3-4 waves per SIMD, profiles/r04_cnn_phase_cycles.txt).  ROWS rows of RW floats (RW = 8 or 16) from W, RPB = 32 / RW rows per
+// block, double buffered in 64 SGPRs; fully unrolled.  want(b): the caller requests whatever else block b needs (LDS values) next to
+// the block's weights; use(row, w): the row's FMAs; pin(): the caller pins its accumulators ("+v") so that no FMA chain is sunk.
+template <int ROWS, int RW, typename Want, typename Use, typename Pin>
+__device__ __forceinline__ void cnn_wstream(cmem_t W, Want want, Use use, Pin pin) {
+    static_assert(RW == 8 || RW == 16, "8 or 16 weights per row");
+    constexpr int RPB = 32 / RW, NB = (ROWS + RPB - 1) / RPB;
+    float wq[2][32];
+    // the table's address as a value of its own: as a member of the kernel-argument block hipcc spilled the whole 8-SGPR tuple to VGPR
+    // lanes and restored it with 16 v_readlane in front of every block's two loads
+    asm volatile("" : "+s"(W));
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wq[0][i] = W[((i / RW) < ROWS ? (i / RW) : ROWS - 1) * RW + i % RW];
+    want(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float (&cur)[32] = wq[b & 1];
+        asm volatile("" :: "s"(cur[0]), "s"(cur[8]), "s"(cur[16]), "s"(cur[24]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int row = RPB * (b + 1) + i / RW;
+                wq[(b + 1) & 1][i] = W[(row < ROWS ? row : ROWS - 1) * RW + i % RW];
+            }
+            want(b + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RPB; ++r)
+            if (RPB * b + r < ROWS) use(RPB * b + r, &cur[r * RW]);
+        pin();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 struct CnnIn {
     const float* maps;        // [S][4][729]: combined, readings, visits, obstacles
     const int64_t* cells;     // [S][A] owner cells (actor) or nullptr (critic)
@@ -125,15 +181,18 @@ struct CnnFetch {
     int loc, pc;
 };
 
+// Backward (NT = 256): G = 9 groups of 27 threads, thread (g, c) takes map rows p = g + 9 i, i < 12.  Because 27 = 3 x 9, row p lies in
+// plane i / 3 at row g + 9 (i % 3) -- no carry for any g < 9 -- so every global offset (243 i floats) and every padded LDS offset
+// ((i / 3) PLANE + 9 (i % 3) rows) is a compile-time constant behind ONE per-thread base and ONE predicate (tid < 243).  The first
+// version tested `e < 4 * MAPC` per element and walked the LDS address with a wrap test: a branch + exec mask per load and ~6 vector
+// instructions per store, a third of K10's vector instructions (profiles/r04_cnn_phase_cycles.txt).
 template <int CIN, int NT>
 __device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch<NT>& f) {
-    constexpr int G = CnnFetch<NT>::G;
-    const float* src = in.maps + (size_t)s * 4 * MAPC;
-    const bool active = threadIdx.x < G * MAPW;
+    static_assert(NT == 256 && CnnFetch<NT>::G == 9 && CnnFetch<NT>::PER_THREAD == 12, "the carry-free row walk assumes 9 groups x 12 rows");
+    const float* src = in.maps + (size_t)s * 4 * MAPC + threadIdx.x;
+    if (threadIdx.x < 9 * MAPW) {
 #pragma unroll
-    for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
-        const int e = threadIdx.x + i * G * MAPW;
-        f.m[i] = (active && e < 4 * MAPC) ? src[e] : 0.0f;
+        for (int i = 0; i < 12; ++i) f.m[i] = src[i * 9 * MAPW];
     }
     f.loc = -1; f.pc = -1;
     if (CIN == 6) {
@@ -144,15 +203,11 @@ __device__ __forceinline__ void cnn_fetch(const CnnIn& in, long long s, CnnFetch
 
 template <int PLANE, int NT>
 __device__ __forceinline__ void cnn_stage(const CnnFetch<NT>& f, float* xp) {
-    constexpr int G = CnnFetch<NT>::G;
     const int g = threadIdx.x / MAPW, c = threadIdx.x - g * MAPW;
-    const bool active = g < G;
-    int r = g, dst = (g + 1) * XP_RS + c + 1;                           // row p = g of plane 0
+    if (threadIdx.x < 9 * MAPW) {
+        float* d = xp + (g + 1) * XP_RS + c + 1;                        // row g of plane 0
 #pragma unroll
-    for (int i = 0; i < CnnFetch<NT>::PER_THREAD; ++i) {
-        if (active && g + i * G < 4 * MAPW) xp[dst] = f.m[i];
-        r += G; dst += G * XP_RS;
-        if (r >= MAPW) { r -= MAPW; dst += PLANE - MAPW * XP_RS; }      // into the next plane (G < 27: one wrap at most)
+        for (int i = 0; i < 12; ++i) d[(i / 3) * PLANE + (i % 3) * 9 * XP_RS] = f.m[i];
     }
 }
 
@@ -237,44 +292,58 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
         __syncthreads();
         CNN_STAMP(1)
         if (own) {
-            // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool
-            float acc[4][C1];
+            // ---- conv1 on the 2x2 block of the cell + bias + ReLU + max-pool.  The 36 weight rows (plane, ky, kx) x 8 output channels stream
+            // through the scalar unit four at a time (cnn_wstream); a plane's 4 x 4 input window is read from LDS one block before its
+            // first tap is used (double buffered); accumulators as explicit pairs (v_pk_fma_f32)
+            v2f accv[4][C1 / 2];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int co = 0; co < C1; ++co) acc[p][co] = 0.0f;
-#pragma unroll 1       // one input channel at a time: bounds the live broadcast weights (18 float4) and the window
-            for (int ci = 0; ci < DP; ++ci) {
-                float win[4][4];
+                for (int co = 0; co < C1 / 2; ++co) accv[p][co] = (v2f){0.0f, 0.0f};
+            {
+                float win[2][4][4];
+                const float* xw = xpi + 2 * py * XP_RS + 2 * px;
+                cnn_wstream<DP * 9, C1>(
+                    w1c,
+                    [&](int b) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 a = *reinterpret_cast<const float2*>(&xpi[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px]);
-                    const float2 b = *reinterpret_cast<const float2*>(&xpi[ci * XP_PLANE + (2 * py + r) * XP_RS + 2 * px + 2]);
-                    win[r][0] = a.x; win[r][1] = a.y; win[r][2] = b.x; win[r][3] = b.y;
-                }
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 4 * b + r;
+                            if (row < DP * 9 && row % 9 == 0) {
+                                const int ci = row / 9;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        float wa[4], wb[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            wa[q] = w1c[((ci * 3 + ky) * 3 + kx) * C1 + q];
-                            wb[q] = w1c[((ci * 3 + ky) * 3 + kx) * C1 + 4 + q];
+                                for (int rr = 0; rr < 4; ++rr) {
+                                    const float2 a = *reinterpret_cast<const float2*>(&xw[ci * XP_PLANE + rr * XP_RS]);
+                                    const float2 c = *reinterpret_cast<const float2*>(&xw[ci * XP_PLANE + rr * XP_RS + 2]);
+                                    win[ci & 1][rr][0] = a.x; win[ci & 1][rr][1] = a.y; win[ci & 1][rr][2] = c.x; win[ci & 1][rr][3] = c.y;
+                                }
+                            }
                         }
+                    },
+                    [&](int row, const float* w) {
+                        const int ci = row / 9, kk = row - ci * 9, ky = kk / 3, kx = kk - ky * 3;
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
-                                const float v = win[i + ky][j + kx];
+                                const float v = win[ci & 1][i + ky][j + kx];
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    acc[i * 2 + j][q] = __builtin_fmaf(wa[q], v, acc[i * 2 + j][q]);
-                                    acc[i * 2 + j][4 + q] = __builtin_fmaf(wb[q], v, acc[i * 2 + j][4 + q]);
-                                }
+                                for (int q = 0; q < C1 / 2; ++q)
+                                    accv[i * 2 + j][q] = __builtin_elementwise_fma((v2f){w[2 * q], w[2 * q + 1]}, (v2f){v, v}, accv[i * 2 + j][q]);
                             }
-                    }
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+#pragma unroll
+                            for (int q = 0; q < C1 / 2; ++q) asm volatile("" : "+v"(accv[p][q]));
+                    });
             }
+            float acc[4][C1];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int co = 0; co < C1; ++co) acc[p][co] = accv[p][co / 2][co & 1];
             if (CIN == 6) {
                 // the one-hot channels: a 1 at input (r, c) adds w[ky][kx] to conv output (r - ky + 1, c - kx + 1); at most four cells
                 // of an image own such a pixel
@@ -326,20 +395,37 @@ __global__ void __launch_bounds__(FW_NT, 4) rs_cnn_fwd_kernel(CnnIn in, const fl
         __syncthreads();
         CNN_STAMP(3)
         if (own) {
-            // ---- conv2 + bias + ReLU
+            // ---- conv2 + bias + ReLU: 72 weight rows (ci, ky, kx) x 16 output channels, two per block; a block's two P1 values are read
+            // from LDS one block ahead
+            v2f acc2v[C2 / 2];
+#pragma unroll
+            for (int co = 0; co < C2 / 2; ++co) acc2v[co] = (v2f){0.0f, 0.0f};
+            {
+                float vq[2][2];
+                const float* ppq = ppi + py * PP_RS + px;
+                cnn_wstream<C1 * 9, C2>(
+                    w2c,
+                    [&](int b) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int row = 2 * b + r < C1 * 9 ? 2 * b + r : C1 * 9 - 1;
+                            const int ci = row / 9, kk = row - ci * 9, ky = kk / 3, kx = kk - ky * 3;
+                            vq[b & 1][r] = ppq[ci * PP_PLANE + ky * PP_RS + kx];
+                        }
+                    },
+                    [&](int row, const float* w) {
+                        const float v = vq[(row / 2) & 1][row & 1];
+#pragma unroll
+                        for (int q = 0; q < C2 / 2; ++q) acc2v[q] = __builtin_elementwise_fma((v2f){w[2 * q], w[2 * q + 1]}, (v2f){v, v}, acc2v[q]);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int q = 0; q < C2 / 2; ++q) asm volatile("" : "+v"(acc2v[q]));
+                    });
+            }
             float acc2[C2];
 #pragma unroll
-            for (int co = 0; co < C2; ++co) acc2[co] = 0.0f;
-#pragma unroll 1
-            for (int ci = 0; ci < C1; ++ci)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float v = ppi[ci * PP_PLANE + (py + ky) * PP_RS + px + kx];
-#pragma unroll
-                        for (int q = 0; q < C2; ++q) acc2[q] = __builtin_fmaf(w2c[((ci * 3 + ky) * 3 + kx) * C2 + q], v, acc2[q]);
-                    }
+            for (int co = 0; co < C2; ++co) acc2[co] = acc2v[co / 2][co & 1];
             uint32_t live = 0u;
 #pragma unroll
             for (int co = 0; co < C2; ++co) {
@@ -367,17 +453,18 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     constexpr int K1 = CIN * 9;
     float* xp = smem;                               // [4 dense planes][28][28] (plane stride XP_PLANE_B)
     float* pp = xp + DP * XP_PLANE_B;               // [8][15][15]   padded P1
-    float* dzp = pp + C1 * PP_PLANE;                // [16][15][15]  padded dZ2
-    float* gbuf = dzp + C2 * PP_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate: output channels 0..12 of conv2
+    float* dzp = pp + C1 * PPB_PLANE;                // [16][15][15]  padded dZ2
+    float* gbuf = dzp + C2 * PPB_PLANE;              // [8][169]      dL/d(pooled) after the ReLU gate: output channels 0..12 of conv2
     float* gbufb = gbuf + C1 * PC;                  // [8][169]      ... and 13..15 (the helper wave's share)
     uint8_t* ambuf = reinterpret_cast<uint8_t*>(gbufb + C1 * PC);     // [169][8]
     const cmem_t w2b = as_cmem(wt + WT_W2B(CIN));   // [(co,ky,kx)][8 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave id as a scalar
     constexpr int NWAVE = CNN_NT_BWD / 64;
-    for (int e = tid; e < DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
+    for (int e = tid; e < DP * XP_PLANE_B + C1 * PPB_PLANE + C2 * PPB_PLANE; e += CNN_NT_BWD) smem[e] = 0.0f;
     __syncthreads();
     const int py = tid / PW, px = tid - py * PW;
     const bool own = tid < PC;
+    const int dp1_cell = tid < 192 ? (int)BWD_SLOT_PIXEL[tid] : 255;      // the pixel this thread takes in the dP1 phase (bank-conflict free)
     // dW2 (+ db2 in column 72) accumulators: 5 column tiles of the [16 co] x [80] product, this wave's share of the pixels
     v4f accw[5];
 #pragma unroll
@@ -407,7 +494,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         const int n = 16 * t + mrow, nn = (n < 72) ? n : 0;
-        boff[t] = (nn / 9) * PP_PLANE + ((nn % 9) / 3) * PP_RS + nn % 3;
+        boff[t] = (nn / 9) * PPB_PLANE + ((nn % 9) / 3) * PPB_RS + nn % 3;
     }
     const int b4mode = (mrow < 8) ? 0 : ((mrow == 8) ? 1 : 2);        // tile 4 only: columns 64..71 taps, 72 = ones (db2), 73.. = zero
     CnnFetch<CNN_NT_BWD> f;
@@ -434,13 +521,13 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         if (own) {
 #pragma unroll
             for (int co = 0; co < 4; ++co) {
-                pp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1a[co];
-                pp[(4 + co) * PP_PLANE + (py + 1) * PP_RS + px + 1] = fp1b[co];
+                pp[co * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = fp1a[co];
+                pp[(4 + co) * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = fp1b[co];
             }
             *reinterpret_cast<uint2*>(ambuf + tid * C1) = fam;
 #pragma unroll
             for (int co = 0; co < C2; ++co)
-                dzp[co * PP_PLANE + (py + 1) * PP_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
+                dzp[co * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
         }
         if (s + gridDim.x < in.S) { cnn_fetch<CIN, CNN_NT_BWD>(in, s + gridDim.x, f); if (CNN_BWD_PREFETCH) fetch_acts(s + gridDim.x); }   // in flight during the compute
         CNN_STAMP(0)
@@ -456,9 +543,9 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 const bool ok = pxl < PC;
                 const int pq = ok ? pxl : (PC - 1);
                 const int y = pq / PW, x = pq - y * PW;
-                const float a = dzp[mrow * PP_PLANE + (y + 1) * PP_RS + x + 1];
+                const float a = dzp[mrow * PPB_PLANE + (y + 1) * PPB_RS + x + 1];
                 av = ok ? a : 0.0f;
-                const float* pyx = pp + y * PP_RS + x;
+                const float* pyx = pp + y * PPB_RS + x;
 #pragma unroll
                 for (int t = 0; t < 5; ++t) bv[t] = pyx[boff[t]];
                 bv[4] = (b4mode == 0) ? bv[4] : ((b4mode == 1) ? 1.0f : 0.0f);
@@ -484,38 +571,62 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         // with all 144 taps on the 169 pixel threads the fourth wave sat idle for the longest phase of the kernel (28 % of it).  The
         // two partial sums land in gbuf / gbufb and are added where they are read (dW1 gathers below).
 #if defined(CNN_ABL) && CNN_ABL == 2
-        if (own) for (int ci = 0; ci < C1; ++ci) { gbuf[ci * PC + tid] = dzp[ci * PP_PLANE + (py + 1) * PP_RS + px + 1]; gbufb[ci * PC + tid] = 0.0f; }
+        if (own) for (int ci = 0; ci < C1; ++ci) { gbuf[ci * PC + tid] = dzp[ci * PPB_PLANE + (py + 1) * PPB_RS + px + 1]; gbufb[ci * PC + tid] = 0.0f; }
         if (false) {
 #else
         {
 #endif
-            auto dp1 = [&](int qy, int qx, int cell_, int co_lo, int co_hi, float* dst) {
+            // rows (co, ky, kx) of 8 weights (ci) stream through the scalar unit, four rows per block; the four dZ2 values a block
+            // multiplies them with are read from LDS one block ahead, next to the block's weights
+            auto dp1 = [&](int qy, int qx, int cell_, auto co_lo_c, auto co_hi_c, float* dst) {
+                constexpr int CO_LO = decltype(co_lo_c)::value, CO_HI = decltype(co_hi_c)::value, ROWS = (CO_HI - CO_LO) * 9, NBLK = (ROWS + 3) / 4;
+                v2f g2[C1 / 2];                              // explicit pairs: v_pk_fma_f32 (the pins below would otherwise split them)
+#pragma unroll
+                for (int ci = 0; ci < C1 / 2; ++ci) g2[ci] = (v2f){0.0f, 0.0f};
+                float vq[2][4];
+                const float* dzq = dzp + CO_LO * PPB_PLANE + (qy + 2) * PPB_RS + qx + 2;
+                auto value_at = [&](int row) -> float {            // row = (co - CO_LO) * 9 + ky * 3 + kx, compile-time after unrolling
+                    const int co = row / 9, kk = row - co * 9, ky = kk / 3, kx = kk - ky * 3;
+                    return dzq[co * PPB_PLANE - ky * PPB_RS - kx];
+                };
+                cnn_wstream<ROWS, C1>(
+                    w2b + CO_LO * 9 * C1,
+                    [&](int b) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vq[b & 1][r] = value_at(4 * b + r < ROWS ? 4 * b + r : ROWS - 1);
+                    },
+                    [&](int row, const float* w) {
+                        const float v = vq[(row / 4) & 1][row & 3];
+#pragma unroll
+                        for (int q = 0; q < C1 / 2; ++q) g2[q] = __builtin_elementwise_fma((v2f){w[2 * q], w[2 * q + 1]}, (v2f){v, v}, g2[q]);
+                    },
+                    [&]() {
+#pragma unroll
+                        for (int q = 0; q < C1 / 2; ++q) asm volatile("" : "+v"(g2[q]));
+                    });
+                (void)NBLK;
                 float g[C1];
 #pragma unroll
-                for (int ci = 0; ci < C1; ++ci) g[ci] = 0.0f;
-#pragma unroll 1
-                for (int co = co_lo; co < co_hi; ++co)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float v = dzp[co * PP_PLANE + (qy + 2 - ky) * PP_RS + qx + 2 - kx];
-#pragma unroll
-                            for (int q = 0; q < C1; ++q) g[q] = __builtin_fmaf(w2b[((co * 3 + ky) * 3 + kx) * C1 + q], v, g[q]);
-                        }
+                for (int ci = 0; ci < C1; ++ci) g[ci] = g2[ci / 2][ci & 1];
                 float gate[C1];                         // all eight reads before the first write: the compiler cannot tell dst from pp
 #pragma unroll
-                for (int ci = 0; ci < C1; ++ci) gate[ci] = pp[ci * PP_PLANE + (qy + 1) * PP_RS + qx + 1];
+                for (int ci = 0; ci < C1; ++ci) gate[ci] = pp[ci * PPB_PLANE + (qy + 1) * PPB_RS + qx + 1];
 #pragma unroll
                 for (int ci = 0; ci < C1; ++ci) dst[ci * PC + cell_] = (gate[ci] > 0.0f) ? g[ci] : 0.0f;
             };
             if (wave < 3) {
-                if (own) dp1(py, px, tid, 0, DP1_SPLIT, gbuf);
+                if (dp1_cell < PC) {
+                    const int qy = dp1_cell / PW;
+                    dp1(qy, dp1_cell - qy * PW, dp1_cell, std::integral_constant<int, 0>{}, std::integral_constant<int, DP1_SPLIT>{}, gbuf);
+                }
             } else {
 #pragma unroll 1
                 for (int k = 0; k < 3; ++k) {
-                    const int cell_ = lane + 64 * k;
-                    if (cell_ < PC) { const int qy = cell_ / PW; dp1(qy, cell_ - qy * PW, cell_, DP1_SPLIT, C2, gbufb); }
+                    const int cell_ = BWD_SLOT_PIXEL[lane + 64 * k];
+                    if (cell_ < PC) {
+                        const int qy = cell_ / PW;
+                        dp1(qy, cell_ - qy * PW, cell_, std::integral_constant<int, DP1_SPLIT>{}, std::integral_constant<int, C2>{}, gbufb);
+                    }
                 }
             }
         }
@@ -629,7 +740,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 
 inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE) + 2 * 9 * C1); }
 inline size_t bwd_lds(int) {
-    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PP_PLANE + C2 * PP_PLANE + 2 * C1 * PC) * 4 + C1 * PC;
+    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PPB_PLANE + C2 * PPB_PLANE + 2 * C1 * PC) * 4 + C1 * PC;
     size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }

@@ -55,6 +55,9 @@ struct PolArgs {
     int64_t* act;          // [N] or null
     float* logp;           // [N] or null
     int N;
+    int xs, ls, us;        // row strides (floats) of x, loc, u: 11 / 2 / 1 for packed rows, A times that for agent a's rows of [N][A][.]
+    int8_t* act8;          // [N][as] or null: the action once more as the env's int8 (rs_step's input row)
+    int as;
 };
 
 __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
@@ -64,8 +67,8 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     const cmem_t W = as_cmem(a_.w);
     float x[NX], h[GH];
 #pragma unroll
-    for (int k = 0; k < RS_OBS_DIM; ++k) x[k] = a_.x[(size_t)ec * RS_OBS_DIM + k];
-    x[RS_OBS_DIM] = a_.loc[(size_t)ec * 2]; x[RS_OBS_DIM + 1] = a_.loc[(size_t)ec * 2 + 1];
+    for (int k = 0; k < RS_OBS_DIM; ++k) x[k] = a_.x[(size_t)ec * a_.xs + k];
+    x[RS_OBS_DIM] = a_.loc[(size_t)ec * a_.ls]; x[RS_OBS_DIM + 1] = a_.loc[(size_t)ec * a_.ls + 1];
 #pragma unroll
     for (int u = 0; u < GH; u += 4) {
         const float4 v = *reinterpret_cast<const float4*>(a_.h + (size_t)ec * GH + u);
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
 #pragma unroll
             for (int o = 0; o < NA; o += 4) *reinterpret_cast<float4*>(a_.logits + (size_t)e * NA + o) = make_float4(lg[o], lg[o + 1], lg[o + 2], lg[o + 3]);
         }
-        if (a_.act || a_.logp) {
+        if (a_.act || a_.logp || a_.act8) {
             float mx = lg[0];
 #pragma unroll
             for (int o = 1; o < NA; ++o) mx = fmaxf(mx, lg[o]);
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
 #pragma unroll
             for (int o = 0; o < NA; ++o) se += expf(lg[o] - mx);
             const float lse = logf(se);
-            const float uu = a_.u ? a_.u[ec] : 0.0f;
+            const float uu = a_.u ? a_.u[(size_t)ec * a_.us] : 0.0f;
             float cdf = 0.0f, lp_sel = (lg[0] - mx) - lse;
             int act = 0;
 #pragma unroll
@@ -138,6 +141,7 @@ __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
             for (int o = 1; o < NA; ++o) if (act == o) lp_sel = (lg[o] - mx) - lse;
             if (live) {
                 if (a_.act) a_.act[e] = act;
+                if (a_.act8) a_.act8[(size_t)e * a_.as] = (int8_t)act;
                 if (a_.logp) a_.logp[e] = lp_sel;
             }
         }
@@ -330,7 +334,18 @@ int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, c
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream) {
     if (!weights || !x || !loc || !h || num_envs < 1) return RS_ERR_INVALID_ARG;
     if ((act || logp) && !u) return RS_ERR_INVALID_ARG;
-    PolArgs a{weights, x, loc, h, u, h_out, logits, value, act, logp, num_envs};
+    PolArgs a{weights, x, loc, h, u, h_out, logits, value, act, logp, num_envs, RS_OBS_DIM, 2, 1, nullptr, 1};
+    hipLaunchKernelGGL(rs_rnn_policy_kernel, dim3((num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_rnn_policy_step_rows(const float* weights, const float* x, int32_t x_stride, const float* loc, int32_t loc_stride, const float* h,
+                            const float* u, int32_t u_stride, float* h_out, float* value, int64_t* act, float* logp, int8_t* act8,
+                            int32_t act8_stride, int32_t num_envs, rs_stream_t stream) {
+    if (!weights || !x || !loc || !h || num_envs < 1 || x_stride < RS_OBS_DIM || loc_stride < 2 || u_stride < 1 || act8_stride < 1)
+        return RS_ERR_INVALID_ARG;
+    if ((act || logp || act8) && !u) return RS_ERR_INVALID_ARG;
+    PolArgs a{weights, x, loc, h, u, h_out, nullptr, value, act, logp, num_envs, x_stride, loc_stride, u_stride, act8, act8_stride};
     hipLaunchKernelGGL(rs_rnn_policy_kernel, dim3((num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

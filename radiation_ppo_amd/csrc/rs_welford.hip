@@ -163,9 +163,126 @@ __global__ void __launch_bounds__(256) rs_store_rows_kernel(StoreArgs a_) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The element-wise bookkeeping of a collector lock-step (train.py:332-548 between the library calls), three launches instead of
+// ~30 (each ~4.6 us inside the replayed graph: half of the RAD-A2C collector's lock-step).  One thread per env; the Welford arithmetic
+// is rs_welford_update_kernel's, operation by operation.
+__device__ __forceinline__ void cs_welford_update(const rs_collect_state& c, int i, double x) {
+    const double cnt = c.w_count[i] + 1.0, m = c.w_mean[i];
+    c.w_count[i] = cnt;
+    if (cnt == 1.0) { c.w_mean[i] = x; return; }
+    const double mn = m + (x - m) / cnt;
+    const double s = c.w_sq[i] + (x - m) * (x - mn);
+    c.w_mean[i] = mn;
+    c.w_sq[i] = s;
+    c.w_std[i] = fmax(sqrt(s / fmax(cnt - 1.0, 1.0)), 1.0);
+}
+
+__device__ __forceinline__ void cs_standardized_row(const rs_collect_state& c, int i, const float* __restrict__ src, float* __restrict__ dst) {
+#pragma unroll
+    for (int k = 1; k < RS_OBS_DIM; ++k) dst[k] = src[k];
+    dst[0] = c.w_count ? (float)(((double)src[0] - c.w_mean[i]) / c.w_std[i]) : src[0];
+}
+
+// x <- obs with the reading standardised by the running statistics (train.py:334-341)
+__global__ void __launch_bounds__(256) rs_collect_pre_kernel(rs_collect_state c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.num_envs * c.num_agents) return;
+    cs_standardized_row(c, i, c.obs + (size_t)i * RS_OBS_DIM, c.x + (size_t)i * RS_OBS_DIM);
+}
+
+// after rs_step: returns, step counters, episode / epoch cut flags (train.py:366-405), Welford update with the new readings (:432-436),
+// the new observation and its standardised form for the bootstrap value (:462-480); the predictor's call counter advances
+__global__ void __launch_bounds__(256) rs_collect_post_step_kernel(rs_collect_state c, int epoch_ended) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= c.num_envs) return;
+    const int A = c.num_agents;
+    bool terminal = false;
+    for (int a = 0; a < A; ++a) {
+        const int i = n * A + a;
+        const float r = c.team_reward ? c.env_team[n] : c.env_reward[i];
+        if (c.reward_used) c.reward_used[i] = r;
+        c.ep_ret[i] += r;
+        terminal = terminal || c.env_done[i] != 0;
+    }
+    const int st = c.steps_in_ep[n] + 1;
+    c.steps_in_ep[n] = st;
+    const bool timeout = st == c.steps_per_episode;
+    const bool over = terminal || timeout;
+    const bool cut = epoch_ended ? true : over;
+    c.over[n] = over ? 1 : 0;
+    c.cut[n] = cut ? 1 : 0;
+    c.boot[n] = (epoch_ended ? cut : timeout) ? 1 : 0;
+    for (int a = 0; a < A; ++a) {
+        const int i = n * A + a;
+        const float* src = c.env_obs + (size_t)i * RS_OBS_DIM;
+        float* dst = c.obs + (size_t)i * RS_OBS_DIM;
+        if (c.w_count) cs_welford_update(c, i, (double)src[0]);
+#pragma unroll
+        for (int k = 0; k < RS_OBS_DIM; ++k) dst[k] = src[k];
+        if (c.xb) cs_standardized_row(c, i, src, c.xb + (size_t)i * RS_OBS_DIM);
+    }
+    if (c.pf_calls) c.pf_calls[n] += 1;
+}
+
+// after rs_reset(cut): the envs that were cut start an episode -- fresh observation, zero return / step count, restarted statistics
+// with the first reading (train.py:504-548), new draw counters for the predictor bank and the GRU's initial state (reset_hidden);
+// the device-side step counter advances
+__global__ void __launch_bounds__(256) rs_collect_post_reset_kernel(rs_collect_state c, int reset_hidden) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && c.t) c.t[0] += 1;
+    if (n >= c.num_envs) return;
+    const int A = c.num_agents;
+    if (c.pf_calls && c.boot[n]) c.pf_calls[n] += 1;            // the bootstrap round's prediction (masked to these envs)
+    if (!c.cut[n]) return;
+    for (int a = 0; a < A; ++a) {
+        const int i = n * A + a;
+        const float* src = c.env_obs + (size_t)i * RS_OBS_DIM;
+        float* dst = c.obs + (size_t)i * RS_OBS_DIM;
+#pragma unroll
+        for (int k = 0; k < RS_OBS_DIM; ++k) dst[k] = src[k];
+        c.ep_ret[i] = 0.0f;
+        if (c.w_count) { c.w_count[i] = 1.0; c.w_mean[i] = (double)src[0]; c.w_sq[i] = 0.0; c.w_std[i] = 1.0; }     // reset + first update
+    }
+    c.steps_in_ep[n] = 0;
+    if (reset_hidden) {
+        if (c.pf_episode) c.pf_episode[n] += 1;
+        if (c.pf_calls) c.pf_calls[n] = 0;
+        if (c.episodes_begun) c.episodes_begun[n] += 1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+static bool collect_ok(const rs_collect_state* c) {
+    return c && c->num_envs >= 1 && c->num_agents >= 1 && c->num_agents <= RS_MAX_AGENTS && c->obs && c->env_obs && c->env_reward && c->env_done &&
+           c->ep_ret && c->steps_in_ep && c->over && c->cut && c->boot && (!c->team_reward || c->env_team) &&
+           ((c->w_count != nullptr) == (c->w_mean != nullptr)) && ((c->w_count != nullptr) == (c->w_sq != nullptr)) &&
+           ((c->w_count != nullptr) == (c->w_std != nullptr));
+}
+
+int rs_collect_pre(const rs_collect_state* c, rs_stream_t stream) {
+    if (!collect_ok(c) || !c->x) return RS_ERR_INVALID_ARG;
+    const int M = c->num_envs * c->num_agents;
+    hipLaunchKernelGGL(rs_collect_pre_kernel, dim3((M + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *c);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_collect_post_step(const rs_collect_state* c, int32_t epoch_ended, rs_stream_t stream) {
+    if (!collect_ok(c) || c->steps_per_episode < 1) return RS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rs_collect_post_step_kernel, dim3((c->num_envs + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *c,
+                       epoch_ended ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_collect_post_reset(const rs_collect_state* c, int32_t reset_hidden, rs_stream_t stream) {
+    if (!collect_ok(c)) return RS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rs_collect_post_reset_kernel, dim3((c->num_envs + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *c,
+                       reset_hidden ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_store_rows(const int64_t* t, const int64_t* act, const float* logp_val_boot, const float* x, const int32_t* src_x, const int32_t* src_y,
                   const float* rew, const uint8_t* cut, const uint8_t* boot, int64_t* buf_act, float* buf_logp, float* buf_val,

@@ -272,6 +272,25 @@ class PredictorBank:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+    # the two kernels alone, for the collectors whose bookkeeping kernels (rs_collect_post_step / _post_reset) keep the draw counters:
+    # `episode` / `calls` are NOT touched here, `mask8` is a uint8 tensor or None, the prediction comes back as the bank's own buffer
+    def predict_kernel(self, obs: torch.Tensor, mask8: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert self.impl == "hip" and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.N, self.A, _lib.RS_OBS_DIM)
+        with _lib.timed("rs_pfgru_step"):
+            _lib.check(self._lib.rs_pfgru_step(self._packed().data_ptr(), obs.data_ptr(), self._hq.data_ptr(), self.p.data_ptr(),
+                                               self._base.data_ptr(), self.episode.data_ptr(), self.calls.data_ptr(),
+                                               None if mask8 is None else mask8.data_ptr(), 1 if self.carry_hidden else 0,
+                                               float(self.cells[0].resamp_alpha), self._pred.data_ptr(), self.N, self.A, self._stream()),
+                       "rs_pfgru_step")
+        return self._pred
+
+    def reset_kernel(self, mask8: Optional[torch.Tensor] = None) -> None:
+        assert self.impl == "hip"
+        with _lib.timed("rs_pfgru_reset"):
+            _lib.check(self._lib.rs_pfgru_reset(self._hq.data_ptr(), self.p.data_ptr(), self._base.data_ptr(), self.episode.data_ptr(),
+                                                self.calls.data_ptr(), None if mask8 is None else mask8.data_ptr(), self.N, self.A,
+                                                self._stream()), "rs_pfgru_reset")
+
     def _packed(self) -> torch.Tensor:
         ver = tuple(p._version for c in self.cells for p in c.parameters())
         if getattr(self, "_pack_ver", None) != ver:

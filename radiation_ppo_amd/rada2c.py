@@ -562,6 +562,18 @@ class RNNAgentPPO:
                                                   ptr(value), ptr(act), ptr(logp), x.shape[0],
                                                   C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "rs_rnn_policy_step")
 
+    def policy_step_rows(self, x, loc, h, u, a: int, value, act=None, logp=None, act8=None) -> None:
+        """K14 on agent a's rows of the collectors' [N, A, .] tensors (no contiguous copies): x [N, A, 11], loc [N, A, 2], u [N, A] or
+        None (value only), h [N, 24] updated in place when an action is drawn; act8 [N, A] int8 receives the action for rs_step."""
+        N, A = x.shape[0], x.shape[1]
+        w = self.policy_weights()
+        fl = lambda t, k: None if t is None else t.data_ptr() + 4 * a * k
+        _lib.check(_lib.load().rs_rnn_policy_step_rows(w.data_ptr(), fl(x, _lib.RS_OBS_DIM), A * _lib.RS_OBS_DIM, fl(loc, 2), 2 * A, h.data_ptr(),
+                                                       fl(u, 1), A, None if u is None else h.data_ptr(), value.data_ptr(),
+                                                       None if act is None else act.data_ptr(), None if logp is None else logp.data_ptr(),
+                                                       None if act8 is None else act8.data_ptr() + a, A, N,
+                                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "rs_rnn_policy_step_rows")
+
     def reduce_pfgru_training(self) -> None:
         """ppo.py:685-689."""
         if self.reduce_pfgru_iters:
@@ -951,6 +963,58 @@ class RNNCollector:
         self.obs = None
         self.started = False
         self.epoch = 0
+        # the lock-step's element-wise bookkeeping as three launches (rs_collect_*; ~30 torch launches before): needs K14 and the fused bank
+        self.use_glue = self.use_k14 and fused_pf
+        self._cs = None
+
+    def _glue_state(self) -> "_lib.RsCollectState":
+        """rs_collect_state over the collector's (fixed-address) buffers, built once the first observation exists."""
+        if self._cs is None:
+            env, dev, N, A = self.env, self.env.device, self.N, self.A
+            self._x_buf = torch.zeros(N, A, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)
+            self._xb_buf = torch.zeros(N, A, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)
+            self._flags = torch.zeros(3, N, dtype=torch.uint8, device=dev)                  # over, cut, boot
+            p = lambda t: t.data_ptr()
+            st = self.stat
+            self._cs = _lib.RsCollectState(N, A, self.L, 0, p(env.obs), p(env.reward), p(env.team), p(env.done), p(self.obs), p(self.ep_ret),
+                                           p(self.steps_in_ep), p(st.count), p(st.mean), p(st.sq), p(st.std), p(self._x_buf), p(self._xb_buf), None,
+                                           p(self._flags[0]), p(self._flags[1]), p(self._flags[2]), p(self.bank.episode), p(self.bank.calls),
+                                           p(self.episodes_begun), p(self._t))
+        return self._cs
+
+    @torch.no_grad()
+    def _step_glued(self, epoch_ended: bool) -> None:
+        """_step with the bookkeeping between the library calls in rs_collect_pre / _post_step / _post_reset: 15 launches per lock-step
+        (pre, uniforms, K11, K14, env step, post_step, K11 + K14 of the bootstrap round, store_rows, epoch_stats, env reset, post_reset,
+        particle-set and GRU-state resets) where the torch composition took ~45.  Same arithmetic, operation by operation."""
+        env, buf, N, A = self.env, self.buf, self.N, self.A
+        lib, cs = _lib.load(), self._glue_state()
+        st = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
+        over, cut, boot = self._flags[0], self._flags[1], self._flags[2]
+        _lib.check(lib.rs_collect_pre(C.byref(cs), st), "rs_collect_pre")                       # train.py:334-341
+        x = self._x_buf
+        env.action_uniforms(self._u)
+        loc = self.bank.predict_kernel(x)                                                      # PFGRU (K11), carried particle sets
+        for a, ag in self.agents.items():
+            ag.policy_step_rows(x, loc, self.h[a], self._u, a, value=self._k_f[a, 1], act=self._k_act[a], logp=self._k_f[a, 0], act8=self._act8)
+        _, rew, _, done, info = env.step(self._act8)
+        _lib.check(lib.rs_collect_post_step(C.byref(cs), 1 if epoch_ended else 0, st), "rs_collect_post_step")
+        locb = self.bank.predict_kernel(self._xb_buf, mask8=boot)                              # train.py:462-487: one more ac.step for the value
+        for a, ag in self.agents.items():
+            ag.policy_step_rows(self._xb_buf, locb, self.h[a], None, a, value=self._k_f[a, 2])
+        _lib.check(lib.rs_store_rows(self._t.data_ptr(), self._k_act.data_ptr(), self._k_f.data_ptr(), x.data_ptr(),
+                                     env.state("src_x").data_ptr(), env.state("src_y").data_ptr(), rew.data_ptr(), cut.data_ptr(), boot.data_ptr(),
+                                     buf.act.data_ptr(), buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(), buf.obs.data_ptr(),
+                                     buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T, st), "rs_store_rows")
+        self._acc.step_and_episodes(info["out_of_bounds"], done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
+        if epoch_ended:
+            env.set_epoch_end()
+        env.reset(cut)
+        _lib.check(lib.rs_collect_post_reset(C.byref(cs), 0 if epoch_ended else 1, st), "rs_collect_post_reset")
+        if not epoch_ended:                                                                    # train.py:505-518 (reset_hidden)
+            self.bank.reset_kernel(cut)
+            _lib.check(lib.rs_gru_h0_reset(self.h.data_ptr(), self.bank._base.data_ptr(), self.episodes_begun.data_ptr(), cut.data_ptr(),
+                                           1.0 / math.sqrt(self.agents[0].agent.hid), N, A, st), "rs_gru_h0_reset")
 
     def _x(self, obs: torch.Tensor) -> torch.Tensor:
         x = obs.clone()
@@ -982,6 +1046,8 @@ class RNNCollector:
     @torch.no_grad()
     def _step(self, epoch_ended: bool) -> None:
         """One lock-step of train.py:332-548 ('rnn' branches) for all envs; row self._t of the buffers is written."""
+        if self.use_glue:
+            return self._step_glued(epoch_ended)
         env, buf, L, N, A = self.env, self.buf, self.L, self.N, self.A
         acc, ti = self._acc, self._t
         put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
@@ -1071,6 +1137,8 @@ class RNNCollector:
                 ag.policy_weights()                                           # re-packed in place after an update
         if self.bank.impl == "hip":
             self.bank._packed()                # the captured K11 launch reads this buffer: update_model changed the PFGRU since
+        if self.use_glue:
+            self._glue_state()                 # its buffers exist before the lock-step is captured
         if self.use_graph and self._graph is None and T > 1:
             side = torch.cuda.Stream(device=self.env.device)                  # library warm-up (GEMM handles) outside the capture
             side.wait_stream(torch.cuda.current_stream(self.env.device))

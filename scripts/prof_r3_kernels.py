@@ -90,7 +90,7 @@ for _ in range(4):
     env.step(acts)
 torch.cuda.synchronize()
 alg["rs_rollout16_kernel<true>"] = 77 * N * T
-alg["rs_step4_kernel"] = 157 * N
+alg["rs_step4_kernel"] = (157 + 48 * float(env.state("num_obs").float().mean().item())) * N     # + rectangles 16 B and cached geodesics 32 B per rectangle
 del col, env, ag
 
 # ---- K13 (one update_model iteration at 1024 envs) + the RAD-A2C collector's kernels

@@ -568,3 +568,41 @@ def test_host_read_returns_the_device_values():
     assert host_read(t) == [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0]
     assert host_read(t * 2) == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]      # the pinned staging buffer is reused
     assert host_read(torch.tensor([1.0, 2.0])) == [1.0, 2.0]            # CPU tensors: plain tolist
+
+
+@pytest.mark.parametrize("A,obst", [(1, 2), (2, 0)])
+def test_glued_lock_step_equals_the_torch_composition(A, obst):
+    """rs_collect_pre / _post_step / _post_reset + rs_rnn_policy_step_rows (15 launches per lock-step) against the torch composition of the
+    same bookkeeping (~45 launches): after two epochs every buffer, the epoch statistics and everything the collector carries (observation,
+    Welford state, returns, step counters, GRU states, particle sets, draw counters) are IDENTICAL, bit for bit, for one and two agents."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.rada2c import RNNAgentPPO, RNNCollector
+    N, T, L = 80, 26, 8
+
+    def run(glue):
+        torch.manual_seed(4)
+        env = RadSearchVec(N, number_agents=A, obstruction_count=obst, enforce_grid_boundaries=True, seed=SEED, env_id_base=32)
+        agents = {a: RNNAgentPPO(id=a, steps_per_epoch=T, steps_per_episode=L, seed=3 + a, train_pi_iters=1, train_pfgru_iters=1) for a in range(A)}
+        with torch.no_grad():
+            for ag in agents.values():
+                for p in ag.agent.pi.parameters():
+                    p.mul_(2.0)
+        col = RNNCollector(env, agents, T, L, use_graph=False)
+        assert col.use_glue
+        col.use_glue = glue
+        out = []
+        for ep in range(2):
+            st = col.collect()
+            out.append({**{k: getattr(col.buf, k).clone() for k in ("obs", "act", "rew", "val", "logp", "last_val", "cut", "adv", "ret", "source_tar")},
+                        **{"stat_" + k: v.clone() for k, v in st.items()},
+                        "c_obs": col.obs.clone(), "c_ret": col.ep_ret.clone(), "c_steps": col.steps_in_ep.clone(), "c_h": col.h.clone(),
+                        "w_count": col.stat.count.clone(), "w_mean": col.stat.mean.clone(), "w_sq": col.stat.sq.clone(), "w_std": col.stat.std.clone(),
+                        "pf_h": col.bank.h.clone(), "pf_p": col.bank.p.clone(), "pf_episode": col.bank.episode.clone(), "pf_calls": col.bank.calls.clone(),
+                        "begun": col.episodes_begun.clone(), "t": col._t.clone()})
+        assert env.error_flags() == 0
+        return out
+    g, e = run(True), run(False)
+    assert int(e[0]["cut"].sum()) > N * A * 2 and float(e[0]["last_val"].abs().sum()) > 0
+    for ep in range(2):
+        for k in e[ep]:
+            assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
