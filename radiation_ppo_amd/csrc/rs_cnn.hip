@@ -490,13 +490,23 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
     // conflict-free (row-major neighbours collided 2-3 way).
     // MFMA operand coordinates of this lane
     const int mrow = lane & 15, mk = lane >> 4;
-    int boff[5];                                    // B column n = 16*tile + mrow -> offset of tap (ci,ky,kx) in the padded P1 planes
+    // float indices (into smem) of this lane's six operands for its first pixel p0 = 4 wave + mk (< 16): A = dZ2[mrow][p], B column
+    // n = 16 tile + mrow = tap (ci, ky, kx) of the padded P1 planes at p.  Tile 4: columns 64..71 are taps, column 72 is the ones column
+    // (db2) and 73..79 are zero -- those lanes read a cell holding 1.0 / a border cell (0.0) and do not advance (m4 = 0)
+    const int p0 = 4 * wave + mk, wy0 = p0 >= PW ? 1 : 0, wx0 = p0 - wy0 * PW;
+    const int off0 = wy0 * PPB_RS + wx0;
+    const int ia0 = (int)(dzp - smem) + mrow * PPB_PLANE + PPB_RS + 1 + off0;
+    int ib0[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         const int n = 16 * t + mrow, nn = (n < 72) ? n : 0;
-        boff[t] = (nn / 9) * PPB_PLANE + ((nn % 9) / 3) * PPB_RS + nn % 3;
+        ib0[t] = (int)(pp - smem) + (nn / 9) * PPB_PLANE + ((nn % 9) / 3) * PPB_RS + nn % 3 + off0;
     }
-    const int b4mode = (mrow < 8) ? 0 : ((mrow == 8) ? 1 : 2);        // tile 4 only: columns 64..71 taps, 72 = ones (db2), 73.. = zero
+    const int m4 = (mrow < 8) ? -1 : 0;
+    float* onec = reinterpret_cast<float*>(ambuf + C1 * PC);          // [1] = 1.0f
+    if (mrow == 8) ib0[4] = (int)(onec - smem);
+    if (mrow > 8) ib0[4] = (int)(pp - smem);                          // a border cell of the padded plane: never written, 0.0
+    if (tid == 0) *onec = 1.0f;
     CnnFetch<CNN_NT_BWD> f;
     v4f fp1a = (v4f){0.f, 0.f, 0.f, 0.f}, fp1b = fp1a;
     float fda2[C2];
@@ -537,31 +547,46 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 #if !(defined(CNN_ABL) && CNN_ABL == 3)
         {
             // operands of step st + NWAVE are read from LDS while the five MFMAs of step st run (one exposed LDS round trip per wave
-            // and image instead of two per step)
-            auto operands = [&](int st, float& av, float (&bv)[5]) {
-                const int pxl = 4 * st + mk;
-                const bool ok = pxl < PC;
-                const int pq = ok ? pxl : (PC - 1);
-                const int y = pq / PW, x = pq - y * PW;
-                const float a = dzp[mrow * PPB_PLANE + (y + 1) * PPB_RS + x + 1];
-                av = ok ? a : 0.0f;
-                const float* pyx = pp + y * PPB_RS + x;
+            // and image instead of two per step).  The lane's pixel 4 st + mk advances by 16 = one row + 3 columns per step, so the six
+            // operand addresses are carried and bumped by one per-lane delta (row wrap: + another row - 13 columns) -- recomputing
+            // y = pixel / 13, x, and six addresses from them cost 43 vector instructions per k-step, a third of the kernel's (round 4).
+            typedef const __attribute__((address_space(3))) char* lptr_t;      // LDS byte addresses, bumped in bytes
+            const lptr_t lbase = (lptr_t)smem;
+            lptr_t qa = lbase + 4 * ia0, qb[5];
+            int wx = wx0, pix = 4 * wave + mk;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) bv[t] = pyx[boff[t]];
-                bv[4] = (b4mode == 0) ? bv[4] : ((b4mode == 1) ? 1.0f : 0.0f);
+            for (int t = 0; t < 5; ++t) qb[t] = lbase + 4 * ib0[t];
+            auto operands = [&](float& av, float (&bv)[5]) {
+                const float a = *(const __attribute__((address_space(3))) float*)qa;
+                av = pix < PC ? a : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) bv[t] = *(const __attribute__((address_space(3))) float*)qb[t];
+                wx += 3;
+                const bool wrap = wx >= PW;
+                const int d = wrap ? 4 * (2 * PPB_RS + 3 - PW) : 4 * (PPB_RS + 3);
+                wx = wrap ? wx - PW : wx;
+                pix += 16;
+                qa += d;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qb[t] += d;
+                qb[4] += d & m4;
             };
-            float av_n = 0.0f, bv_n[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            operands(wave, av_n, bv_n);                             // wave < NWAVE <= 43
+            // two steps per trip (registers ping-pong, no moves); waves 0-2 take 11 steps, wave 3 ten
+            float av0, bv0[5], av1 = 0.0f, bv1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            operands(av0, bv0);
+            const int nst = (43 - wave + NWAVE - 1) / NWAVE;
 #pragma unroll 1
-            for (int st = wave; st < 43; st += NWAVE) {
-                const float av = av_n;
-                float bv[5];
-#pragma unroll
-                for (int t = 0; t < 5; ++t) bv[t] = bv_n[t];
-                if (st + NWAVE < 43) operands(st + NWAVE, av_n, bv_n);
+            for (int j = 0; j < nst; j += 2) {
+                if (j + 1 < nst) operands(av1, bv1);
                 __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // the next step's six DS reads go out first ...
 #pragma unroll
-                for (int t = 0; t < 5; ++t) accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], accw[t], 0, 0, 0);
+                for (int t = 0; t < 5; ++t) accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[t], accw[t], 0, 0, 0);
+                if (j + 1 < nst) {
+                    if (j + 2 < nst) operands(av0, bv0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[t], accw[t], 0, 0, 0);
+                }
             }
         }
 #endif
@@ -740,7 +765,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
 
 inline size_t fwd_lds(int) { return sizeof(float) * (size_t)(FW_IMG * (DP * XP_PLANE + C1 * PP_PLANE) + 2 * 9 * C1); }
 inline size_t bwd_lds(int) {
-    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PPB_PLANE + C2 * PPB_PLANE + 2 * C1 * PC) * 4 + C1 * PC;
+    size_t img = (size_t)(DP * XP_PLANE_B + C1 * PPB_PLANE + C2 * PPB_PLANE + 2 * C1 * PC) * 4 + C1 * PC + 16;     // + the ones cell
     size_t red = (size_t)(CNN_NT_BWD * ((DP / 2) * 9 + 1) + (CNN_NT_BWD / 64) * 16 * 80 + 2 * C1 * 9) * 4;
     return ((img > red ? img : red) + 15) & ~(size_t)15;
 }
