@@ -402,10 +402,11 @@ int rs_gru_backward(const float* dhs, const float* hs, const float* gates, const
 int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, const float* h, const float* u, float* h_out,
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream);
 /* The same step reading agent a's rows straight out of the collectors' [N][A][.] tensors (x_stride / loc_stride / u_stride: floats
- * between consecutive envs' rows) and writing the action once more as int8 into rs_step's action row (act8 [N][act8_stride]). */
+ * between consecutive envs' rows) and writing the action once more as int8 into rs_step's action row (act8 [N][act8_stride]);
+ * mask [N] or NULL: only the envs with mask != 0 are evaluated (the bootstrap round of a lock-step: the others' outputs are untouched). */
 int rs_rnn_policy_step_rows(const float* weights, const float* x, int32_t x_stride, const float* loc, int32_t loc_stride, const float* h,
                             const float* u, int32_t u_stride, float* h_out, float* value, int64_t* act, float* logp, int8_t* act8,
-                            int32_t act8_stride, int32_t num_envs, rs_stream_t stream);
+                            int32_t act8_stride, const uint8_t* mask, int32_t num_envs, rs_stream_t stream);
 
 /* The heads of the RAD-A2C actor-critic, update_rada2c's per-sample loss (algos/multiagent/ppo.py:1191-1234: PPO-clip surrogate on
  * the policy head, vf_coef x squared error on the value head; the entropy term carries no gradient) and their back-propagation,
@@ -492,6 +493,14 @@ typedef struct {
     uint8_t* over; uint8_t* cut; uint8_t* boot;                        /* [N] */
     int64_t* pf_episode; int64_t* pf_calls; int64_t* episodes_begun;   /* [N] or NULL */
     int64_t* t;                   /* [1] device-side step counter, or NULL */
+    /* copies of what rs_store_rows / rs_epoch_stats read of the env's output rows, taken by rs_collect_post_step so that rs_reset (which
+     * rewrites those rows and moves the sources of the cut envs) may run beside the bootstrap round on another stream; all or none NULL */
+    const uint8_t* env_oob;       /* [N][A] info.out_of_bounds */
+    const int32_t* env_src_x; const int32_t* env_src_y;               /* [N] */
+    uint8_t* done_copy; uint8_t* oob_copy;                            /* [N][A] */
+    int32_t* src_copy;            /* [2][N] */
+    int64_t* complete_len;        /* [N] or NULL: t + 1 of the env's last episode end so far in the epoch (what sample() of the 'cnn' update
+                                   * counts, algos/multiagent/ppo.py:754-764); set by rs_collect_post_step where over != 0 */
 } rs_collect_state;
 int rs_collect_pre(const rs_collect_state* c, rs_stream_t stream);
 int rs_collect_post_step(const rs_collect_state* c, int32_t epoch_ended, rs_stream_t stream);

@@ -35,7 +35,8 @@ class RsCollectState(C.Structure):
     """rs_collect_state (include/radsearch.h)."""
     _fields_ = [("num_envs", C.c_int32), ("num_agents", C.c_int32), ("steps_per_episode", C.c_int32), ("team_reward", C.c_int32)] + [
         (n, C.c_void_p) for n in ("env_obs", "env_reward", "env_team", "env_done", "obs", "ep_ret", "steps_in_ep", "w_count", "w_mean", "w_sq",
-                                  "w_std", "x", "xb", "reward_used", "over", "cut", "boot", "pf_episode", "pf_calls", "episodes_begun", "t")]
+                                  "w_std", "x", "xb", "reward_used", "over", "cut", "boot", "pf_episode", "pf_calls", "episodes_begun", "t",
+                                  "env_oob", "env_src_x", "env_src_y", "done_copy", "oob_copy", "src_copy", "complete_len")]
 
 
 class RsMlpParams(C.Structure):
@@ -113,7 +114,7 @@ SYMBOLS = [
     ("rs_pfgru_train", C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("rs_rnn_policy_step", C.c_int, [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
     ("rs_rnn_policy_step_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("rs_collect_pre", C.c_int, [C.POINTER(RsCollectState), C.c_void_p]),
     ("rs_collect_post_step", C.c_int, [C.POINTER(RsCollectState), C.c_int32, C.c_void_p]),
     ("rs_collect_post_reset", C.c_int, [C.POINTER(RsCollectState), C.c_int32, C.c_void_p]),

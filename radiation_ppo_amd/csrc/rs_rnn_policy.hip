@@ -58,12 +58,14 @@ struct PolArgs {
     int xs, ls, us;        // row strides (floats) of x, loc, u: 11 / 2 / 1 for packed rows, A times that for agent a's rows of [N][A][.]
     int8_t* act8;          // [N][as] or null: the action once more as the env's int8 (rs_step's input row)
     int as;
+    const uint8_t* mask;   // [N] or null: only these envs are wanted (the bootstrap round); a wave without one leaves at once
 };
 
 __global__ void __launch_bounds__(64) rs_rnn_policy_kernel(PolArgs a_) {
     const int e = blockIdx.x * 64 + threadIdx.x;
-    const bool live = e < a_.N;
-    const int ec = live ? e : a_.N - 1;                    // idle lanes shadow the last env, store nothing
+    const bool live = e < a_.N && (a_.mask == nullptr || a_.mask[e] != 0);
+    if (!__any(live)) return;
+    const int ec = e < a_.N ? e : a_.N - 1;                // idle lanes shadow a real env, store nothing
     const cmem_t W = as_cmem(a_.w);
     float x[NX], h[GH];
 #pragma unroll
@@ -334,18 +336,18 @@ int rs_rnn_policy_step(const float* weights, const float* x, const float* loc, c
                        float* logits, float* value, int64_t* act, float* logp, int32_t num_envs, rs_stream_t stream) {
     if (!weights || !x || !loc || !h || num_envs < 1) return RS_ERR_INVALID_ARG;
     if ((act || logp) && !u) return RS_ERR_INVALID_ARG;
-    PolArgs a{weights, x, loc, h, u, h_out, logits, value, act, logp, num_envs, RS_OBS_DIM, 2, 1, nullptr, 1};
+    PolArgs a{weights, x, loc, h, u, h_out, logits, value, act, logp, num_envs, RS_OBS_DIM, 2, 1, nullptr, 1, nullptr};
     hipLaunchKernelGGL(rs_rnn_policy_kernel, dim3((num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
 int rs_rnn_policy_step_rows(const float* weights, const float* x, int32_t x_stride, const float* loc, int32_t loc_stride, const float* h,
                             const float* u, int32_t u_stride, float* h_out, float* value, int64_t* act, float* logp, int8_t* act8,
-                            int32_t act8_stride, int32_t num_envs, rs_stream_t stream) {
+                            int32_t act8_stride, const uint8_t* mask, int32_t num_envs, rs_stream_t stream) {
     if (!weights || !x || !loc || !h || num_envs < 1 || x_stride < RS_OBS_DIM || loc_stride < 2 || u_stride < 1 || act8_stride < 1)
         return RS_ERR_INVALID_ARG;
     if ((act || logp || act8) && !u) return RS_ERR_INVALID_ARG;
-    PolArgs a{weights, x, loc, h, u, h_out, nullptr, value, act, logp, num_envs, x_stride, loc_stride, u_stride, act8, act8_stride};
+    PolArgs a{weights, x, loc, h, u, h_out, nullptr, value, act, logp, num_envs, x_stride, loc_stride, u_stride, act8, act8_stride, mask};
     hipLaunchKernelGGL(rs_rnn_policy_kernel, dim3((num_envs + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }

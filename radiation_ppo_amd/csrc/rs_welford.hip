@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(256) rs_collect_post_step_kernel(rs_collect_st
         if (c.reward_used) c.reward_used[i] = r;
         c.ep_ret[i] += r;
         terminal = terminal || c.env_done[i] != 0;
+        if (c.done_copy) { c.done_copy[i] = c.env_done[i]; c.oob_copy[i] = c.env_oob[i]; }
     }
+    if (c.done_copy) { c.src_copy[n] = c.env_src_x[n]; c.src_copy[c.num_envs + n] = c.env_src_y[n]; }
     const int st = c.steps_in_ep[n] + 1;
     c.steps_in_ep[n] = st;
     const bool timeout = st == c.steps_per_episode;
@@ -213,6 +215,7 @@ __global__ void __launch_bounds__(256) rs_collect_post_step_kernel(rs_collect_st
     c.over[n] = over ? 1 : 0;
     c.cut[n] = cut ? 1 : 0;
     c.boot[n] = (epoch_ended ? cut : timeout) ? 1 : 0;
+    if (c.complete_len && over) c.complete_len[n] = c.t[0] + 1;
     for (int a = 0; a < A; ++a) {
         const int i = n * A + a;
         const float* src = c.env_obs + (size_t)i * RS_OBS_DIM;
@@ -260,7 +263,9 @@ static bool collect_ok(const rs_collect_state* c) {
     return c && c->num_envs >= 1 && c->num_agents >= 1 && c->num_agents <= RS_MAX_AGENTS && c->obs && c->env_obs && c->env_reward && c->env_done &&
            c->ep_ret && c->steps_in_ep && c->over && c->cut && c->boot && (!c->team_reward || c->env_team) &&
            ((c->w_count != nullptr) == (c->w_mean != nullptr)) && ((c->w_count != nullptr) == (c->w_sq != nullptr)) &&
-           ((c->w_count != nullptr) == (c->w_std != nullptr));
+           ((c->w_count != nullptr) == (c->w_std != nullptr)) &&
+           ((c->done_copy != nullptr) == (c->oob_copy != nullptr)) && ((c->done_copy != nullptr) == (c->src_copy != nullptr)) &&
+           (c->done_copy == nullptr || (c->env_oob && c->env_src_x && c->env_src_y));
 }
 
 int rs_collect_pre(const rs_collect_state* c, rs_stream_t stream) {

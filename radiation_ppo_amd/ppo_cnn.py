@@ -24,7 +24,7 @@ from .envs import RadSearchVec
 from .maps import CNNActor, CNNCritic, HeatMaps, actor_stack_from
 from .pfgru import PredictorBank, hash_bits, hash_uniform
 from .ppo import (EpochStats, RolloutBuffer, UpdateResult, _world, check_minibatch, host_read, normalize_advantages,
-                  reduce_grads_and_stats, reject_unknown_kwargs)
+                  reduce_grads_and_stats, reject_unknown_kwargs, side_stream)
 
 
 def minibatch_weights(complete_len: torch.Tensor, T: int, minibatch: int, key: torch.Tensor, n_total: int) -> torch.Tensor:
@@ -278,6 +278,7 @@ class CNNCollector:
         self._row_act = torch.zeros(self.N, self.A, dtype=torch.int64, device=dev)
         self._row_f = torch.zeros(3, self.N, self.A, dtype=torch.float32, device=dev)      # logp, val, last_val of the step
         self.obs = None
+        self._cs = None                                 # rs_collect_state: the lock-step's bookkeeping kernels (see _glue_state)
         # CNNBase.model (RADTEAM_core.py:1790-1795): one PFGRU cell per owner, all envs at once
         self.predictor: Optional[PredictorBank] = None
         if use_predictor:
@@ -295,6 +296,78 @@ class CNNCollector:
     def actor_stack_from(self, shared: torch.Tensor, cells: torch.Tensor, pcells: torch.Tensor, a: int) -> torch.Tensor:
         return actor_stack_from(shared, cells, pcells, a)
 
+    @property
+    def use_glue(self) -> bool:
+        return self.env.device.type == "cuda" and (self.predictor is None or self.predictor.impl == "hip")
+
+    def _glue_state(self) -> "_lib.RsCollectState":
+        """rs_collect_state over the collector's buffers (rs_collect_post_step / _post_reset: the lock-step's returns, counters, cut
+        flags, observation copies and draw counters in two launches instead of ~27 element-wise ones)."""
+        if self._cs is None:
+            env, dev, N, A = self.env, self.env.device, self.N, self.A
+            self._flags = torch.zeros(3, N, dtype=torch.uint8, device=dev)                  # over, cut, boot
+            self._rew_used = torch.zeros(N, A, dtype=torch.float32, device=dev)
+            p = lambda t: None if t is None else t.data_ptr()
+            pf = self.predictor
+            self._cs = _lib.RsCollectState(N, A, self.L, 1 if self.team_reward else 0, p(env.obs), p(env.reward), p(env.team), p(env.done),
+                                           p(self.obs), p(self.ep_ret), p(self.steps_in_ep), None, None, None, None, None, None, p(self._rew_used),
+                                           p(self._flags[0]), p(self._flags[1]), p(self._flags[2]), p(pf.episode if pf else None),
+                                           p(pf.calls if pf else None), None, p(self._t), None, None, None, None, None, None, p(self.complete_len))
+        return self._cs
+
+    @torch.no_grad()
+    def _round_glued(self, mask8: Optional[torch.Tensor] = None):
+        pred = None
+        if self.predictor is not None:
+            pred = self.predictor.predict_kernel(self.obs, mask8=mask8)
+        self.maps.update(self.obs, pred=pred, mask=mask8)
+        return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
+
+    @torch.no_grad()
+    def _step_glued(self, epoch_ended: bool) -> None:
+        """_step with the element-wise bookkeeping between the library calls in rs_collect_post_step / _post_reset."""
+        env, buf, N, A = self.env, self.buf, self.N, self.A
+        acc, ti = self._acc, self._t
+        lib, cs = _lib.load(), self._glue_state()
+        st = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
+        over, cut, boot = self._flags[0], self._flags[1], self._flags[2]
+        put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
+        critic, cells, pcells = self._round_glued()
+        put(self.shared, critic); put(self.cells, cells); put(self.pcells, pcells)
+        env.action_uniforms(self._u)
+        v_shared = None
+        for a, ag in self.agents.items():
+            act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
+            if not ag.global_critic or v_shared is None:          # one evaluation serves every owner of a global critic
+                v_shared = ag._values((critic,))
+            self._row_act[:, a] = act
+            self._row_f[0, :, a] = logp
+            self._row_f[1, :, a] = v_shared
+            self._act8[:, a] = act.to(torch.int8)
+        put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
+        put(buf.obs, self.obs)
+        _, _, _, done, info = env.step(self._act8)
+        _lib.check(lib.rs_collect_post_step(C.byref(cs), 1 if epoch_ended else 0, st), "rs_collect_post_step")
+        put(buf.rew, self._rew_used)
+        put(buf.cut, cut.unsqueeze(1).expand(N, A).contiguous())
+        # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480)
+        critic_b, _, _ = self._round_glued(mask8=boot)
+        bc = boot.view(torch.bool)
+        vb = None
+        for a, ag in self.agents.items():
+            if not ag.global_critic or vb is None:
+                vb = ag._values((critic_b,))
+            self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
+        put(buf.last_val, self._row_f[2])
+        acc.step_and_episodes(info["out_of_bounds"], done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
+        if epoch_ended:
+            env.set_epoch_end()
+        self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
+        env.reset(cut)
+        _lib.check(lib.rs_collect_post_reset(C.byref(cs), 1, st), "rs_collect_post_reset")
+        if self.predictor is not None:
+            self.predictor.reset_kernel(cut)                            # hidden = ac.reset_hidden() (test_cnn/train.py:770)
+
     @torch.no_grad()
     def _round(self, mask: Optional[torch.Tensor] = None):
         """One select_action round of every owner's MapsBuffer (maps updated once, shared by all owners): returns
@@ -308,6 +381,8 @@ class CNNCollector:
     @torch.no_grad()
     def _step(self, epoch_ended: bool) -> None:
         """One lock-step of train.py:332-548 for all envs; row self._t of the buffers is written, then self._t advances."""
+        if self.use_glue and getattr(self, "glue", True):
+            return self._step_glued(epoch_ended)
         env, buf, L, N, A = self.env, self.buf, self.L, self.N, self.A
         acc, ti = self._acc, self._t
         put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
@@ -369,10 +444,12 @@ class CNNCollector:
         self._acc.zero_()
         self.complete_len.zero_()
         self._t.zero_()
+        if self.use_glue and getattr(self, "glue", True):
+            self._glue_state()
         if self.use_graph and self._graph is None and T > 1:
             # lazy library initialisation (rocBLAS handles / workspaces) must not fall into the capture: evaluate the
             # networks once on the current maps (pure functions, no collector state changes), then record the step
-            side = torch.cuda.Stream(device=self.env.device)
+            side = side_stream(self.env.device)                               # library warm-up (GEMM handles) outside the capture
             side.wait_stream(torch.cuda.current_stream(self.env.device))
             with torch.cuda.stream(side):
                 critic = self.maps.shared_maps()

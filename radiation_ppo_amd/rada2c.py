@@ -30,6 +30,7 @@ loop's last episode, :1274); (iii) several agents are independent copies, each f
 import bisect
 import ctypes as C
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
@@ -43,7 +44,7 @@ from . import _lib
 from .envs import RadSearchVec
 from .pfgru import PFGRUCell, PredictorBank, _s64, hash_normal, hash_uniform
 from .ppo import (DeviceWelford, EpochStats, RolloutBuffer, UpdateResult, _world, check_minibatch, host_read, normalize_advantages,
-                  reduce_grads_and_stats, reject_unknown_kwargs)
+                  reduce_grads_and_stats, reject_unknown_kwargs, side_stream)
 
 
 def _mlp_tanh(sizes) -> nn.Sequential:
@@ -562,16 +563,18 @@ class RNNAgentPPO:
                                                   ptr(value), ptr(act), ptr(logp), x.shape[0],
                                                   C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "rs_rnn_policy_step")
 
-    def policy_step_rows(self, x, loc, h, u, a: int, value, act=None, logp=None, act8=None) -> None:
+    def policy_step_rows(self, x, loc, h, u, a: int, value, act=None, logp=None, act8=None, mask8=None) -> None:
         """K14 on agent a's rows of the collectors' [N, A, .] tensors (no contiguous copies): x [N, A, 11], loc [N, A, 2], u [N, A] or
-        None (value only), h [N, 24] updated in place when an action is drawn; act8 [N, A] int8 receives the action for rs_step."""
+        None (value only), h [N, 24] updated in place when an action is drawn; act8 [N, A] int8 receives the action for rs_step;
+        mask8 [N] uint8: only those envs are evaluated (the bootstrap round)."""
         N, A = x.shape[0], x.shape[1]
         w = self.policy_weights()
         fl = lambda t, k: None if t is None else t.data_ptr() + 4 * a * k
         _lib.check(_lib.load().rs_rnn_policy_step_rows(w.data_ptr(), fl(x, _lib.RS_OBS_DIM), A * _lib.RS_OBS_DIM, fl(loc, 2), 2 * A, h.data_ptr(),
                                                        fl(u, 1), A, None if u is None else h.data_ptr(), value.data_ptr(),
                                                        None if act is None else act.data_ptr(), None if logp is None else logp.data_ptr(),
-                                                       None if act8 is None else act8.data_ptr() + a, A, N,
+                                                       None if act8 is None else act8.data_ptr() + a, A,
+                                                       None if mask8 is None else mask8.data_ptr(), N,
                                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "rs_rnn_policy_step_rows")
 
     def reduce_pfgru_training(self) -> None:
@@ -743,6 +746,9 @@ class RNNAgentPPO:
         last = 0.0
         self.k13_particle_steps = []                                               # this update's launches only
         chunk = self._k13_chunk(B.X.shape[0], E)
+        # (Producing iteration it + 1's draws -- rs_pfgru_draws, 2.3 ms of HBM writes, keys only -- on the side stream under iteration it's
+        # walk was built and measured in round 4: no gain.  The backward walk holds the whole register file, so the draws can only
+        # run beside the forward walk, which is VALU bound like they are.)
         for it in range(self.train_pfgru_iters):
             self.model_optimizer.zero_grad(set_to_none=True)
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
@@ -777,8 +783,7 @@ class RNNAgentPPO:
         on the PFGRU's weights only -- not on the policy being updated -- so iteration it + 1's passes (VALU bound, the whole chip)
         run under iteration it's GRU recurrence (66 waves, latency bound), its head / loss kernels and the Adam step.
         Returns ([loc per chunk], event)."""
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+        self._side = side_stream(self.device)
         main = torch.cuda.current_stream(self.device)
         if it == 0:
             self._side.wait_stream(main)                                     # the batch and update_model's weights are final
@@ -974,12 +979,17 @@ class RNNCollector:
             self._x_buf = torch.zeros(N, A, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)
             self._xb_buf = torch.zeros(N, A, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)
             self._flags = torch.zeros(3, N, dtype=torch.uint8, device=dev)                  # over, cut, boot
+            self._rew_used = torch.zeros(N, A, dtype=torch.float32, device=dev)
+            self._done_oob = torch.zeros(2, N, A, dtype=torch.uint8, device=dev)            # copies of the env's done / out_of_bounds rows
+            self._src_copy = torch.zeros(2, N, dtype=torch.int32, device=dev)
+            self._side = side_stream(dev)
             p = lambda t: t.data_ptr()
             st = self.stat
             self._cs = _lib.RsCollectState(N, A, self.L, 0, p(env.obs), p(env.reward), p(env.team), p(env.done), p(self.obs), p(self.ep_ret),
-                                           p(self.steps_in_ep), p(st.count), p(st.mean), p(st.sq), p(st.std), p(self._x_buf), p(self._xb_buf), None,
-                                           p(self._flags[0]), p(self._flags[1]), p(self._flags[2]), p(self.bank.episode), p(self.bank.calls),
-                                           p(self.episodes_begun), p(self._t))
+                                           p(self.steps_in_ep), p(st.count), p(st.mean), p(st.sq), p(st.std), p(self._x_buf), p(self._xb_buf),
+                                           p(self._rew_used), p(self._flags[0]), p(self._flags[1]), p(self._flags[2]), p(self.bank.episode),
+                                           p(self.bank.calls), p(self.episodes_begun), p(self._t), p(env.oob), p(env.state("src_x")),
+                                           p(env.state("src_y")), p(self._done_oob[0]), p(self._done_oob[1]), p(self._src_copy), None)
         return self._cs
 
     @torch.no_grad()
@@ -997,19 +1007,27 @@ class RNNCollector:
         loc = self.bank.predict_kernel(x)                                                      # PFGRU (K11), carried particle sets
         for a, ag in self.agents.items():
             ag.policy_step_rows(x, loc, self.h[a], self._u, a, value=self._k_f[a, 1], act=self._k_act[a], logp=self._k_f[a, 0], act8=self._act8)
-        _, rew, _, done, info = env.step(self._act8)
+        env.step(self._act8)
         _lib.check(lib.rs_collect_post_step(C.byref(cs), 1 if epoch_ended else 0, st), "rs_collect_post_step")
+        # the env's reset (a latency-bound ~50 us: one env's spawn is a 15 k-instruction chain on four lanes) runs on a side stream
+        # beside the bootstrap round, the buffer rows and the statistics: those read post_step's COPIES of the reward / done / out-of-
+        # bounds rows and of the source positions, which the reset rewrites
+        main = torch.cuda.current_stream(env.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            if epoch_ended:
+                env.set_epoch_end()
+            env.reset(cut)
         locb = self.bank.predict_kernel(self._xb_buf, mask8=boot)                              # train.py:462-487: one more ac.step for the value
         for a, ag in self.agents.items():
-            ag.policy_step_rows(self._xb_buf, locb, self.h[a], None, a, value=self._k_f[a, 2])
+            ag.policy_step_rows(self._xb_buf, locb, self.h[a], None, a, value=self._k_f[a, 2], mask8=boot)
         _lib.check(lib.rs_store_rows(self._t.data_ptr(), self._k_act.data_ptr(), self._k_f.data_ptr(), x.data_ptr(),
-                                     env.state("src_x").data_ptr(), env.state("src_y").data_ptr(), rew.data_ptr(), cut.data_ptr(), boot.data_ptr(),
-                                     buf.act.data_ptr(), buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(), buf.obs.data_ptr(),
-                                     buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T, st), "rs_store_rows")
-        self._acc.step_and_episodes(info["out_of_bounds"], done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
-        if epoch_ended:
-            env.set_epoch_end()
-        env.reset(cut)
+                                     self._src_copy[0].data_ptr(), self._src_copy[1].data_ptr(), self._rew_used.data_ptr(), cut.data_ptr(),
+                                     boot.data_ptr(), buf.act.data_ptr(), buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(),
+                                     buf.obs.data_ptr(), buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T, st),
+                   "rs_store_rows")
+        self._acc.step_and_episodes(self._done_oob[1], self._done_oob[0], self.ep_ret, self.steps_in_ep, over.view(torch.bool))
+        main.wait_stream(self._side)
         _lib.check(lib.rs_collect_post_reset(C.byref(cs), 0 if epoch_ended else 1, st), "rs_collect_post_reset")
         if not epoch_ended:                                                                    # train.py:505-518 (reset_hidden)
             self.bank.reset_kernel(cut)
@@ -1140,7 +1158,7 @@ class RNNCollector:
         if self.use_glue:
             self._glue_state()                 # its buffers exist before the lock-step is captured
         if self.use_graph and self._graph is None and T > 1:
-            side = torch.cuda.Stream(device=self.env.device)                  # library warm-up (GEMM handles) outside the capture
+            side = side_stream(self.env.device)                               # library warm-up (GEMM handles) outside the capture
             side.wait_stream(torch.cuda.current_stream(self.env.device))
             with torch.cuda.stream(side):
                 x = self._x(self.obs)

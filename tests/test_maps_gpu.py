@@ -505,3 +505,39 @@ def test_heat_maps_bin_the_noisy_coordinates_when_coord_noise_is_on():
         acts = rng.integers(0, 8, size=(N, A)).astype(np.int8)
         obs_t = env.step(torch.from_numpy(acts).cuda())[0]
     assert moved > 0 and int(hm.field("err").max().item()) == 0
+
+
+@pytest.mark.parametrize("team", [True, False])
+def test_cnn_glued_lock_step_equals_the_torch_composition(team):
+    """The RAD-TEAM lock-step with its bookkeeping in rs_collect_post_step / _post_reset against the element-wise torch composition: every
+    buffer, the stored maps and cells, complete_len, the epoch statistics and the carried state (observation, returns, step counters,
+    predictor draw counters) identical after two epochs -- team reward (global critic) and individual rewards."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L = 32, 3, 24, 7
+
+    def run(glue):
+        torch.manual_seed(8)
+        env = RadSearchVec(N, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=SEED, env_id_base=32)
+        gc = CNNCritic().cuda() if team else None
+        agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=torch.optim.Adam(gc.parameters(), lr=1e-3) if team else None)
+                  for i in range(A)}
+        col = CNNCollector(env, agents, T, L, global_critic_flag=team, use_graph=False)
+        assert col.use_glue
+        col.glue = glue
+        out = []
+        for _ in range(2):
+            st = col.collect()
+            out.append({**{k: getattr(col.buf, k).clone() for k in ("obs", "act", "rew", "val", "logp", "last_val", "cut", "adv", "ret")},
+                        "shared": col.shared.clone(), "cells": col.cells.clone(), "pcells": col.pcells.clone(),
+                        "complete_len": col.complete_len.clone(), **{"stat_" + k: v.clone() for k, v in st.items()},
+                        "c_obs": col.obs.clone(), "c_ret": col.ep_ret.clone(), "c_steps": col.steps_in_ep.clone(), "t": col._t.clone(),
+                        "pf_episode": col.predictor.episode.clone(), "pf_calls": col.predictor.calls.clone()})
+        assert env.error_flags() == 0
+        return out
+    g, e = run(True), run(False)
+    assert int(e[0]["cut"].sum()) > N * A
+    for ep in range(2):
+        for k in e[ep]:
+            assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
