@@ -420,6 +420,22 @@ int rs_a2c_heads_loss(const float* weights, const float* hs, const int64_t* act,
                       const float* sample_weight, float* dhs, float* dfac, float* tfac, float* stats, int64_t samples, double clip_ratio,
                       double vf_coef, rs_stream_t stream);
 
+/* The forward trunk as the collectors use it: rs_cnn_trunk_prepare re-arranges a network's convolution weights into wscratch
+ * (rs_cnn_trunk_scratch_floats floats) once per epoch, rs_cnn_trunk_infer is then ONE launch per select_action round (a2 only). */
+int rs_cnn_trunk_prepare(int32_t in_channels, const float* w1, const float* b1, const float* w2, const float* b2, float* wscratch,
+                         rs_stream_t stream);
+int rs_cnn_trunk_infer(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent, int64_t num_samples,
+                       const float* wscratch, float* a2, rs_stream_t stream);
+
+/* The RAD-TEAM heads behind their first Linear layer (CNNBase.select_action, RADTEAM_core.py:1838-1892; Actor :1000-1023, Critic
+ * :1250-1271): y1 [N][32] = Linear(2704, 32)(a2), pre-activation -> ReLU -> Linear(32, 16) (w2 [16][32], b2) -> ReLU -> Linear(16, out_dim)
+ * (w3 [out_dim][16], b3).  out_dim = 8: the action logits -> log-softmax, inverse-CDF draw on u [n * u_stride] (a = #{j < 7: cdf_j <= u}),
+ * act [N] int64, logp [N], act8 [n * act8_stride] (any NULL: not written).  out_dim = 1: the state value, written value_copies times at
+ * value_stride floats.  mask [N] or NULL: only those envs. */
+int rs_cnn_head(const float* y1, const float* w2, const float* b2, const float* w3, const float* b3, int32_t out_dim, const float* u,
+                int32_t u_stride, int64_t* act, float* logp, int8_t* act8, int32_t act8_stride, float* value, int32_t value_copies,
+                int64_t value_stride, const uint8_t* mask, int32_t num_envs, rs_stream_t stream);
+
 /* The PPO-clip actor loss of the RAD-TEAM update behind the logits (AgentPPO.compute_loss_pi, algos/multiagent/ppo.py:966-1003) and its
  * derivative, one pass: logits [S][8], act [S], adv [S], logp_old [S], sample_weight [S] ->
  *   dlogits [S][8] = d (-sum_s w_s min(ratio_s adv_s, clip(ratio_s) adv_s)) / d logits,

@@ -125,6 +125,10 @@ SYMBOLS = [
     ("rs_epoch_stats", C.c_int, [C.c_void_p] * 13 + [C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_a2c_heads_loss", C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_double, C.c_double, C.c_void_p]),
     ("rs_actor_loss", C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_double, C.c_void_p]),
+    ("rs_cnn_trunk_prepare", C.c_int, [C.c_int32] + [C.c_void_p] * 6),
+    ("rs_cnn_trunk_infer", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rs_cnn_head", C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                              C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     ("rs_store_rows", C.c_int, [C.c_void_p] * 17 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_gru_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("rs_gru_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -817,6 +817,30 @@ int rs_cnn_trunk_forward(const float* maps, const int64_t* cells, const int64_t*
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 
+/* The forward trunk for a collector's lock-steps: the weights are re-arranged ONCE per epoch (rs_cnn_trunk_prepare -> wscratch) and every
+ * select_action round is one launch (rs_cnn_trunk_infer; no activations for a backward pass are kept). */
+int rs_cnn_trunk_prepare(int32_t in_channels, const float* w1, const float* b1, const float* w2, const float* b2, float* wscratch,
+                         rs_stream_t stream) {
+    if ((in_channels != 6 && in_channels != 4) || !w1 || !b1 || !w2 || !b2 || !wscratch) return RS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rs_cnn_prep_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in_channels, w1, b1, w2, b2, wscratch);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
+int rs_cnn_trunk_infer(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent, int64_t num_samples,
+                       const float* wscratch, float* a2, rs_stream_t stream) {
+    if (!maps || !wscratch || !a2 || num_samples < 0) return RS_ERR_INVALID_ARG;
+    if (agent >= 0 && (!cells || !pcells || agent >= num_agents)) return RS_ERR_INVALID_ARG;
+    if (num_samples == 0) return RS_OK;
+    CnnIn in{maps, cells, pcells, num_agents, agent, (long long)num_samples};
+    hipStream_t s = (hipStream_t)stream;
+    const long long rounds = (num_samples + FW_IMG - 1) / FW_IMG;
+    if (agent >= 0) hipLaunchKernelGGL(rs_cnn_fwd_kernel<6>, dim3(cnn_grid(rs_cnn_fwd_kernel<6>, FW_NT, fwd_lds(6), rounds)), dim3(FW_NT), fwd_lds(6), s,
+                                       in, wscratch, a2, (float*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr);
+    else hipLaunchKernelGGL(rs_cnn_fwd_kernel<4>, dim3(cnn_grid(rs_cnn_fwd_kernel<4>, FW_NT, fwd_lds(4), rounds)), dim3(FW_NT), fwd_lds(4), s, in,
+                            wscratch, a2, (float*)nullptr, (uint8_t*)nullptr, (uint16_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
 int rs_cnn_trunk_backward(const float* maps, const int64_t* cells, const int64_t* pcells, int32_t num_agents, int32_t agent,
                           int64_t num_samples, const float* w2, const float* da2, const uint16_t* relu_mask, const float* p1,
                           const uint8_t* amax, float* slab, float* wscratch, rs_stream_t stream) {

@@ -69,9 +69,97 @@ __global__ void __launch_bounds__(256) rs_actor_loss_kernel(const float* __restr
     }
 }
 
+// The RAD-TEAM heads behind their first Linear layer, for the collector's select_action (RADTEAM_core.py:1838-1892) on every env at once:
+// y1 = Linear(2704, 32)(a2) comes from the BLAS library (pre-activation); here ReLU -> Linear(32, 16) -> ReLU -> Linear(16, OUT) and
+//   OUT = 8: log-softmax, the inverse-CDF draw on the env's uniform (Categorical.sample as CNNAgentPPO.act composes it: a = #{j < 7 :
+//            cdf_j <= u}), log-probability of the drawn action -- the collector did this with ~14 element-wise launches per agent;
+//   OUT = 1: the state value, written `copies` times at a stride (one row per agent that shares a global critic).
+// One env per lane; the 16 x 32 and OUT x 16 weights are wave uniform (scalar loads).
+typedef const float __attribute__((address_space(4))) * hd_cmem_t;
+__device__ __forceinline__ hd_cmem_t hd_cmem(const float* p) { return (hd_cmem_t)(uintptr_t)p; }
+
+template <int OUT>
+__global__ void __launch_bounds__(64) rs_cnn_head_kernel(const float* __restrict__ y1, const float* w2_, const float* b2_, const float* w3_,
+                                                         const float* b3_, const float* __restrict__ u, int us, int64_t* __restrict__ act,
+                                                         float* __restrict__ logp, int8_t* __restrict__ act8, int as,
+                                                         float* __restrict__ value, int copies, long long vstride,
+                                                         const uint8_t* __restrict__ mask, int N) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const bool live = e < N && (mask == nullptr || mask[e] != 0);
+    if (!__any(live)) return;
+    const int ec = e < N ? e : N - 1;
+    const hd_cmem_t w2 = hd_cmem(w2_), b2 = hd_cmem(b2_), w3 = hd_cmem(w3_), b3 = hd_cmem(b3_);
+    float h1[32];
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(y1 + (size_t)ec * 32 + k);
+        h1[k] = fmaxf(v.x, 0.0f); h1[k + 1] = fmaxf(v.y, 0.0f); h1[k + 2] = fmaxf(v.z, 0.0f); h1[k + 3] = fmaxf(v.w, 0.0f);
+    }
+    float h2[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float s = b2[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s = __builtin_fmaf(w2[o * 32 + k], h1[k], s);
+        h2[o] = fmaxf(s, 0.0f);
+    }
+    float lg[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        float s = b3[o];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = __builtin_fmaf(w3[o * 16 + k], h2[k], s);
+        lg[o] = s;
+    }
+    if (OUT == 1) {
+        if (live)
+            for (int c = 0; c < copies; ++c) value[(size_t)c * vstride + e] = lg[0];
+        return;
+    }
+    float mx = lg[0];
+#pragma unroll
+    for (int o = 1; o < OUT; ++o) mx = fmaxf(mx, lg[o]);
+    float se = 0.0f;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) se += expf(lg[o] - mx);
+    const float lse = logf(se);
+    const float uu = u[(size_t)ec * us];
+    float cdf = 0.0f, lp_sel = (lg[0] - mx) - lse;
+    int a = 0;
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+        const float lp = (lg[o] - mx) - lse;
+        cdf += expf(lp);
+        if (o < OUT - 1 && cdf <= uu) a = o + 1;
+    }
+#pragma unroll
+    for (int o = 1; o < OUT; ++o) if (a == o) lp_sel = (lg[o] - mx) - lse;
+    if (live) {
+        if (act) act[e] = a;
+        if (logp) logp[e] = lp_sel;
+        if (act8) act8[(size_t)e * as] = (int8_t)a;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rs_cnn_head(const float* y1, const float* w2, const float* b2, const float* w3, const float* b3, int32_t out_dim, const float* u,
+                int32_t u_stride, int64_t* act, float* logp, int8_t* act8, int32_t act8_stride, float* value, int32_t value_copies,
+                int64_t value_stride, const uint8_t* mask, int32_t num_envs, rs_stream_t stream) {
+    if (!y1 || !w2 || !b2 || !w3 || !b3 || num_envs < 1 || (out_dim != 8 && out_dim != 1)) return RS_ERR_INVALID_ARG;
+    if (out_dim == 8 && (!u || u_stride < 1 || act8_stride < 1)) return RS_ERR_INVALID_ARG;
+    if (out_dim == 1 && (!value || value_copies < 1)) return RS_ERR_INVALID_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dim == 8)
+        hipLaunchKernelGGL(rs_cnn_head_kernel<8>, dim3((num_envs + 63) / 64), dim3(64), 0, s, y1, w2, b2, w3, b3, u, u_stride, act, logp, act8,
+                           act8_stride, value, value_copies, (long long)value_stride, mask, num_envs);
+    else
+        hipLaunchKernelGGL(rs_cnn_head_kernel<1>, dim3((num_envs + 63) / 64), dim3(64), 0, s, y1, w2, b2, w3, b3, u, u_stride, act, logp, act8,
+                           act8_stride, value, value_copies, (long long)value_stride, mask, num_envs);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
 
 int rs_actor_loss(const float* logits, const int64_t* act, const float* adv, const float* logp_old, const float* sample_weight,
                   float* dlogits, float* stats, int64_t samples, double clip_ratio, rs_stream_t stream) {

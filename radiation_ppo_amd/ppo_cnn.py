@@ -323,42 +323,110 @@ class CNNCollector:
         self.maps.update(self.obs, pred=pred, mask=mask8)
         return self.maps.shared_maps(), self.maps.field("cell").long(), self.maps.field("pred_cell").long()
 
+    @property
+    def use_heads(self) -> bool:
+        """The select_action round of every agent as trunk (one prepared launch) + BLAS Linear(2704, 32) + rs_cnn_head, buffer rows by
+        rs_store_rows: the walls-enforced 27 x 27 maps only (the trunk kernels' size)."""
+        return self.use_glue and tuple(self.maps.map_dimensions) == (27, 27) and getattr(self, "heads", True)
+
+    def _prepare_heads(self) -> None:
+        """Once per epoch (the networks do not change during collection): every agent's convolution weights in the trunk kernel's
+        layout; the fixed-address buffers of the fused round."""
+        lib, dev, N, A = _lib.load(), self.env.device, self.N, self.A
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if getattr(self, "_wt", None) is None:
+            self._wt = {a: torch.empty(lib.rs_cnn_trunk_scratch_floats(6), dtype=torch.float32, device=dev) for a in self.agents}
+            self._wt_c = {a: torch.empty(lib.rs_cnn_trunk_scratch_floats(4), dtype=torch.float32, device=dev) for a in self.agents}
+            self._a2 = torch.empty(N, 2704, dtype=torch.float32, device=dev)
+            self._k_act = torch.zeros(A, N, dtype=torch.int64, device=dev)
+            self._k_f = torch.zeros(A, 3, N, dtype=torch.float32, device=dev)                   # logp, value, bootstrap value
+            self._x_buf = torch.zeros(N, A, _lib.RS_OBS_DIM, dtype=torch.float32, device=dev)   # the step's observation (buffer row)
+        for a, ag in self.agents.items():
+            m = ag.pi.actor
+            _lib.check(lib.rs_cnn_trunk_prepare(6, m[0].weight.data_ptr(), m[0].bias.data_ptr(), m[3].weight.data_ptr(), m[3].bias.data_ptr(),
+                                                self._wt[a].data_ptr(), st), "rs_cnn_trunk_prepare")
+            if not ag.global_critic or a == min(self.agents):
+                c = ag.critic.critic
+                _lib.check(lib.rs_cnn_trunk_prepare(4, c[0].weight.data_ptr(), c[0].bias.data_ptr(), c[3].weight.data_ptr(), c[3].bias.data_ptr(),
+                                                    self._wt_c[a].data_ptr(), st), "rs_cnn_trunk_prepare")
+
+    def _values_fused(self, critic_maps, slot: int, mask8=None) -> None:
+        """V(s) of every env into self._k_f[:, slot] (slot 1: the step's value, 2: the bootstrap value): one evaluation serves every
+        owner of a global critic (train.py:191-206)."""
+        lib, N, A = _lib.load(), self.N, self.A
+        st = C.c_void_p(torch.cuda.current_stream(self.env.device).cuda_stream)
+        first = min(self.agents)
+        for a, ag in self.agents.items():
+            if ag.global_critic and a != first:
+                continue
+            c = ag.critic.critic
+            _lib.check(lib.rs_cnn_trunk_infer(critic_maps.data_ptr(), None, None, 0, -1, N, self._wt_c[a].data_ptr(), self._a2.data_ptr(), st),
+                       "rs_cnn_trunk_infer")
+            y1 = torch.nn.functional.linear(self._a2, c[6].weight, c[6].bias)
+            copies = A if ag.global_critic else 1
+            _lib.check(lib.rs_cnn_head(y1.data_ptr(), c[8].weight.data_ptr(), c[8].bias.data_ptr(), c[10].weight.data_ptr(), c[10].bias.data_ptr(), 1,
+                                       None, 1, None, None, None, 1, self._k_f[0 if ag.global_critic else a, slot].data_ptr(), copies, 3 * N,
+                                       None if mask8 is None else mask8.data_ptr(), N, st), "rs_cnn_head")
+
     @torch.no_grad()
     def _step_glued(self, epoch_ended: bool) -> None:
-        """_step with the element-wise bookkeeping between the library calls in rs_collect_post_step / _post_reset."""
+        """_step with the element-wise bookkeeping between the library calls in rs_collect_post_step / _post_reset and (27 x 27 maps) every
+        agent's select_action as trunk + Linear + rs_cnn_head, the buffer rows by rs_store_rows: ~40 launches per lock-step where the
+        torch composition took ~110."""
         env, buf, N, A = self.env, self.buf, self.N, self.A
         acc, ti = self._acc, self._t
         lib, cs = _lib.load(), self._glue_state()
         st = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
         over, cut, boot = self._flags[0], self._flags[1], self._flags[2]
         put = lambda dst, row: dst.index_copy_(0, ti, row.unsqueeze(0))
+        heads = self.use_heads
         critic, cells, pcells = self._round_glued()
         put(self.shared, critic); put(self.cells, cells); put(self.pcells, pcells)
         env.action_uniforms(self._u)
-        v_shared = None
-        for a, ag in self.agents.items():
-            act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
-            if not ag.global_critic or v_shared is None:          # one evaluation serves every owner of a global critic
-                v_shared = ag._values((critic,))
-            self._row_act[:, a] = act
-            self._row_f[0, :, a] = logp
-            self._row_f[1, :, a] = v_shared
-            self._act8[:, a] = act.to(torch.int8)
-        put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
-        put(buf.obs, self.obs)
+        if heads:
+            self._x_buf.copy_(self.obs)
+            for a, ag in self.agents.items():
+                m = ag.pi.actor
+                _lib.check(lib.rs_cnn_trunk_infer(critic.data_ptr(), cells.data_ptr(), pcells.data_ptr(), A, a, N, self._wt[a].data_ptr(),
+                                                  self._a2.data_ptr(), st), "rs_cnn_trunk_infer")
+                y1 = torch.nn.functional.linear(self._a2, m[6].weight, m[6].bias)
+                _lib.check(lib.rs_cnn_head(y1.data_ptr(), m[8].weight.data_ptr(), m[8].bias.data_ptr(), m[10].weight.data_ptr(), m[10].bias.data_ptr(), 8,
+                                           self._u.data_ptr() + 4 * a, A, self._k_act[a].data_ptr(), self._k_f[a, 0].data_ptr(),
+                                           self._act8.data_ptr() + a, A, None, 1, 0, None, N, st), "rs_cnn_head")
+            self._values_fused(critic, 1)
+        else:
+            v_shared = None
+            for a, ag in self.agents.items():
+                act, logp = ag.act((critic, cells, pcells, a), self._u[:, a])
+                if not ag.global_critic or v_shared is None:          # one evaluation serves every owner of a global critic
+                    v_shared = ag._values((critic,))
+                self._row_act[:, a] = act
+                self._row_f[0, :, a] = logp
+                self._row_f[1, :, a] = v_shared
+                self._act8[:, a] = act.to(torch.int8)
+            put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
+            put(buf.obs, self.obs)
         _, _, _, done, info = env.step(self._act8)
         _lib.check(lib.rs_collect_post_step(C.byref(cs), 1 if epoch_ended else 0, st), "rs_collect_post_step")
-        put(buf.rew, self._rew_used)
-        put(buf.cut, cut.unsqueeze(1).expand(N, A).contiguous())
         # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480)
         critic_b, _, _ = self._round_glued(mask8=boot)
-        bc = boot.view(torch.bool)
-        vb = None
-        for a, ag in self.agents.items():
-            if not ag.global_critic or vb is None:
-                vb = ag._values((critic_b,))
-            self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
-        put(buf.last_val, self._row_f[2])
+        if heads:
+            self._values_fused(critic_b, 2, mask8=boot)
+            _lib.check(lib.rs_store_rows(ti.data_ptr(), self._k_act.data_ptr(), self._k_f.data_ptr(), self._x_buf.data_ptr(),
+                                         env.state("src_x").data_ptr(), env.state("src_y").data_ptr(), self._rew_used.data_ptr(), cut.data_ptr(),
+                                         boot.data_ptr(), buf.act.data_ptr(), buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(),
+                                         buf.obs.data_ptr(), buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T, st),
+                       "rs_store_rows")
+        else:
+            put(buf.rew, self._rew_used)
+            put(buf.cut, cut.unsqueeze(1).expand(N, A).contiguous())
+            bc = boot.view(torch.bool)
+            vb = None
+            for a, ag in self.agents.items():
+                if not ag.global_critic or vb is None:
+                    vb = ag._values((critic_b,))
+                self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
+            put(buf.last_val, self._row_f[2])
         acc.step_and_episodes(info["out_of_bounds"], done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
         if epoch_ended:
             env.set_epoch_end()
@@ -446,6 +514,8 @@ class CNNCollector:
         self._t.zero_()
         if self.use_glue and getattr(self, "glue", True):
             self._glue_state()
+            if self.use_heads:
+                self._prepare_heads()
         if self.use_graph and self._graph is None and T > 1:
             # lazy library initialisation (rocBLAS handles / workspaces) must not fall into the capture: evaluate the
             # networks once on the current maps (pure functions, no collector state changes), then record the step

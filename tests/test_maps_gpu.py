@@ -526,6 +526,7 @@ def test_cnn_glued_lock_step_equals_the_torch_composition(team):
         col = CNNCollector(env, agents, T, L, global_critic_flag=team, use_graph=False)
         assert col.use_glue
         col.glue = glue
+        col.heads = False             # the fused select_action round is compared on its own below (float32 summation order differs)
         out = []
         for _ in range(2):
             st = col.collect()
@@ -541,3 +542,50 @@ def test_cnn_glued_lock_step_equals_the_torch_composition(team):
     for ep in range(2):
         for k in e[ep]:
             assert torch.equal(g[ep][k], e[ep][k]), (ep, k)
+
+
+@pytest.mark.parametrize("team", [True, False])
+def test_cnn_fused_select_action_round_equals_the_module_path(team):
+    """rs_cnn_trunk_infer + BLAS Linear(2704, 32) + rs_cnn_head + rs_store_rows (the collector's default on 27 x 27 maps) against the
+    module path (ConvTrunk + nn.Linear layers + the torch sampling tail): on the first lock-step, where both collectors see the same
+    state, log-probabilities and values agree to float32 summation order, the drawn actions are the same except where the uniform falls
+    within that noise of a CDF value, and after a whole epoch the fused collector's buffers hold exactly what its own rows say (actions
+    in range, log-probability = log-softmax of the module's logits at the stored action, value = the module's value)."""
+    from radiation_ppo_amd.envs import RadSearchVec
+    from radiation_ppo_amd.maps import CNNCritic
+    from radiation_ppo_amd.ppo_cnn import CNNAgentPPO, CNNCollector
+    N, A, T, L = 64, 3, 12, 7
+
+    def run(heads):
+        torch.manual_seed(8)
+        env = RadSearchVec(N, number_agents=A, obstruction_count=2, enforce_grid_boundaries=True, seed=SEED, env_id_base=32)
+        gc = CNNCritic().cuda() if team else None
+        agents = {i: CNNAgentPPO(id=i, GlobalCritic=gc, GlobalCriticOptimizer=torch.optim.Adam(gc.parameters(), lr=1e-3) if team else None)
+                  for i in range(A)}
+        with torch.no_grad():
+            for ag in agents.values():
+                for p in list(ag.pi.actor[6:].parameters()):
+                    p.mul_(3.0)                                   # visibly non-uniform policies
+        col = CNNCollector(env, agents, T, L, global_critic_flag=team, use_graph=False)
+        col.heads = heads
+        assert col.use_heads == heads
+        col.collect()
+        return col, agents
+    cf, af = run(True)
+    cm, _ = run(False)
+    same = cf.buf.act[0] == cm.buf.act[0]
+    assert float(same.float().mean()) > 0.99
+    assert torch.allclose(cf.buf.logp[0][same], cm.buf.logp[0][same], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(cf.buf.val[0], cm.buf.val[0], rtol=1e-4, atol=2e-5)
+    assert torch.equal(cf.buf.obs[0], cm.buf.obs[0]) and torch.equal(cf.shared[0], cm.shared[0])
+    # the fused collector's own epoch: every stored row against the modules evaluated on the stored maps
+    assert int(cf.buf.act.min()) >= 0 and int(cf.buf.act.max()) <= 7
+    for t in (0, 5, T - 1):
+        for a, ag in af.items():
+            logits = ag.pi.logits_from_maps(cf.shared[t], cf.cells[t], cf.pcells[t], a)
+            lp = torch.log_softmax(logits, dim=-1).gather(-1, cf.buf.act[t, :, a].unsqueeze(-1)).squeeze(-1)
+            assert torch.allclose(cf.buf.logp[t, :, a], lp, rtol=1e-4, atol=2e-5), (t, a)
+            v = ag.critic.value_from_maps(cf.shared[t])
+            assert torch.allclose(cf.buf.val[t, :, a], v, rtol=1e-4, atol=2e-5), (t, a)
+    boot = cf.buf.last_val != 0
+    assert int(boot.sum()) > 0 and bool((cf.buf.cut[boot.any(dim=2)] == 1).all())
