@@ -307,12 +307,15 @@ class CNNCollector:
             env, dev, N, A = self.env, self.env.device, self.N, self.A
             self._flags = torch.zeros(3, N, dtype=torch.uint8, device=dev)                  # over, cut, boot
             self._rew_used = torch.zeros(N, A, dtype=torch.float32, device=dev)
+            self._done_oob = torch.zeros(2, N, A, dtype=torch.uint8, device=dev)            # copies of the env's done / out_of_bounds rows
+            self._src_copy = torch.zeros(2, N, dtype=torch.int32, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             pf = self.predictor
             self._cs = _lib.RsCollectState(N, A, self.L, 1 if self.team_reward else 0, p(env.obs), p(env.reward), p(env.team), p(env.done),
                                            p(self.obs), p(self.ep_ret), p(self.steps_in_ep), None, None, None, None, None, None, p(self._rew_used),
                                            p(self._flags[0]), p(self._flags[1]), p(self._flags[2]), p(pf.episode if pf else None),
-                                           p(pf.calls if pf else None), None, p(self._t), None, None, None, None, None, None, p(self.complete_len))
+                                           p(pf.calls if pf else None), None, p(self._t), p(env.oob), p(env.state("src_x")), p(env.state("src_y")),
+                                           p(self._done_oob[0]), p(self._done_oob[1]), p(self._src_copy), p(self.complete_len))
         return self._cs
 
     @torch.no_grad()
@@ -406,14 +409,24 @@ class CNNCollector:
                 self._act8[:, a] = act.to(torch.int8)
             put(buf.act, self._row_act); put(buf.logp, self._row_f[0]); put(buf.val, self._row_f[1])
             put(buf.obs, self.obs)
-        _, _, _, done, info = env.step(self._act8)
+        env.step(self._act8)
         _lib.check(lib.rs_collect_post_step(C.byref(cs), 1 if epoch_ended else 0, st), "rs_collect_post_step")
+        done, oob_now = self._done_oob[0], self._done_oob[1]           # post_step's copies: the env's own rows are rewritten by the reset
         # bootstrap: ac.step(observations) once more for the envs that time out / are cut (train.py:462-480)
         critic_b, _, _ = self._round_glued(mask8=boot)
+        # the heat maps have seen the agents' last positions: from here the env's reset (latency bound, ~110 us) runs on the side stream
+        # beside the critic's bootstrap evaluation, the buffer rows and the statistics (which read post_step's copies)
+        main = torch.cuda.current_stream(env.device)
+        side = side_stream(env.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if epoch_ended:
+                env.set_epoch_end()
+            env.reset(cut)
         if heads:
             self._values_fused(critic_b, 2, mask8=boot)
             _lib.check(lib.rs_store_rows(ti.data_ptr(), self._k_act.data_ptr(), self._k_f.data_ptr(), self._x_buf.data_ptr(),
-                                         env.state("src_x").data_ptr(), env.state("src_y").data_ptr(), self._rew_used.data_ptr(), cut.data_ptr(),
+                                         self._src_copy[0].data_ptr(), self._src_copy[1].data_ptr(), self._rew_used.data_ptr(), cut.data_ptr(),
                                          boot.data_ptr(), buf.act.data_ptr(), buf.logp.data_ptr(), buf.val.data_ptr(), buf.last_val.data_ptr(),
                                          buf.obs.data_ptr(), buf.source_tar.data_ptr(), buf.rew.data_ptr(), buf.cut.data_ptr(), N, A, self.T, st),
                        "rs_store_rows")
@@ -427,11 +440,9 @@ class CNNCollector:
                     vb = ag._values((critic_b,))
                 self._row_f[2, :, a] = torch.where(bc, vb, torch.zeros_like(vb))
             put(buf.last_val, self._row_f[2])
-        acc.step_and_episodes(info["out_of_bounds"], done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
-        if epoch_ended:
-            env.set_epoch_end()
+        acc.step_and_episodes(oob_now, done, self.ep_ret, self.steps_in_ep, over.view(torch.bool))
         self.maps.reset(cut)                                             # ac.reset_agent() (train.py:537-540)
-        env.reset(cut)
+        main.wait_stream(side)
         _lib.check(lib.rs_collect_post_reset(C.byref(cs), 1, st), "rs_collect_post_reset")
         if self.predictor is not None:
             self.predictor.reset_kernel(cut)                            # hidden = ac.reset_hidden() (test_cnn/train.py:770)
