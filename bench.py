@@ -496,7 +496,7 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
         fl = 2.0 * 2619 * sum(k11_units[-n:]) / n
         ms = sum(kp[-n:]) / n
         tf = fl / (ms * 1e-3) / 1e12
-        t11, src11 = unit_traffic("rs_pfgru_kernel")
+        t11, src11 = unit_traffic("rs_pfgru_kernel<false, 4>")          # per (episode, step) of the four-step launch
         out["roofline_pfgru_step"] = {"bound": "mfma", "kernel": "rs_pfgru_kernel (K11), per pass of the policy loop (rs_pfgru_pass)", "achieved": tf,
                                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                       "traffic": None if t11 is None else t11 * sum(k11_units[-n:]) / n / 40.0, "traffic_source": src11,

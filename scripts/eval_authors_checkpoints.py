@@ -29,10 +29,15 @@ def main(runs=100):
             sets = load_test_environments_npz(os.path.join(G, f"testset_obs{k}_{snr}.npz"))
             # `og` was trained by the ORIGINAL RAD-A2C code, whose env generator measures I / r^2 (algos/test_environment/eval/test_env_gen.py:37-38);
             # the multi-agent env this build mirrors measures I / r as written (rad_search_env.py:501): both are evaluated
-            for falloff in (("reference", "inverse_square") if tag == "og" else ("reference",)):
+            # carry: the reference's EpisodeRunner.run keeps `hiddens` across the Monte-Carlo runs of an environment (evaluate.py:357,
+            # :455-470; carry_hidden_across_runs=True reproduces it: runs in sequence on one lane); fresh: every run starts from a new
+            # hidden state (all runs as parallel lanes -- what round 3 measured)
+            variants = [("reference", True), ("reference", False)] + ([("inverse_square", True)] if tag == "og" else [])
+            for falloff, carry in variants:
                 t0 = time.time()
-                _, s = run_test_environments(ag, sets, montecarlo_runs=runs, steps_per_episode=120, obstruction_count=k, seed=2, falloff=falloff)
-                out["evaluation"][f"{tag}/obs{k}_{snr}" + ("" if falloff == "reference" else "/inverse_square")] = {
+                _, s = run_test_environments(ag, sets, montecarlo_runs=runs, steps_per_episode=120, obstruction_count=k, seed=2, falloff=falloff,
+                                             carry_hidden_across_runs=carry)
+                out["evaluation"][f"{tag}/obs{k}_{snr}" + ("" if falloff == "reference" else "/inverse_square") + ("/carry_hidden" if carry else "/fresh_hidden")] = {
                     "success_rate": s["success_rate"], "successful_episode_length_median": s["successful_episode_length_median"],
                     "total_episode_length_median": s["total_episode_length_median"],
                     "successful_episode_return_median": s["successful_episode_return_median"],
