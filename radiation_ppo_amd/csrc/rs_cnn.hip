@@ -534,7 +534,11 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 pp[co * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = fp1a[co];
                 pp[(4 + co) * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = fp1b[co];
             }
-            *reinterpret_cast<uint2*>(ambuf + tid * C1) = fam;
+            {   // arg-max codes 0..3 (row << 1 | column of the 2 x 2 pool window) -> the window's byte offset (row * 28 + column) * 4, per byte
+                const uint32_t e0 = ((fam.x >> 1) & 0x01010101u) * (4u * XP_RS) + (fam.x & 0x01010101u) * 4u;
+                const uint32_t e1 = ((fam.y >> 1) & 0x01010101u) * (4u * XP_RS) + (fam.y & 0x01010101u) * 4u;
+                *reinterpret_cast<uint2*>(ambuf + tid * C1) = make_uint2(e0, e1);
+            }
 #pragma unroll
             for (int co = 0; co < C2; ++co)
                 dzp[co * PPB_PLANE + (py + 1) * PPB_RS + px + 1] = ((fmask >> co) & 1u) ? fda2[co] : 0.0f;     // ReLU gate
@@ -662,38 +666,40 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
         // cell adds zeros; the phase is instruction-issue bound, so the index work is shared by CG channels)
 #if !(defined(CNN_ABL) && CNN_ABL == 1)
         {
-            // software-pipelined by hand: the next cell's gradient / arg-max reads are in flight while this cell's 18 window values are
-            // read in ONE round trip and accumulated.  (The compiler's own schedule, tuned for register pressure, waited for every
-            // ds_read before the FMA that uses it: ~12 exposed LDS latencies per cell, a fifth of the kernel.)
-            int cy = grp % PW, cx = grp / PW;                           // cell e = grp + 16 k of the column-major walk: (e % 13, e / 13)
-            auto cell_inputs = [&](int cy_, int cx_, float& gv_, int& off_) {
-                const int cid = cy_ * PW + cx_;
-                const float ga = gbuf[co1 * PC + cid], gb = gbufb[co1 * PC + cid];
-                const int am = ambuf[cid * C1 + co1];
-                gv_ = ga + gb;
-                off_ = (2 * cy_ + (am >> 1)) * XP_RS + 2 * cx_ + (am & 1);
-            };
-            float gv_n; int off_n;
-            cell_inputs(cy, cx, gv_n, off_n);
+            // One ROW of pooled cells per group (cy = grp < 13; groups 13..15 idle): consecutive cells are one gradient float, eight
+            // arg-max bytes and two input columns apart, so the walk is three pointer bumps, and the arg-max is stored as the window's byte offset (ambuf, encoded at staging).  Per cell: 21 LDS reads, 9 packed FMAs
+            // and ~8 other vector instructions.  (Rolled loop with three pointer bumps: fully unrolled, hipcc hoisted the loads of several cells and spilled 284 B.  Round 3 walked the cells column-major with stride 16 and rebuilt cell index, row,
+            // column, window offset and the arg-max decode per cell: ~30 vector instructions around the same 9 FMAs, a third of the
+            // kernel's vector instructions -- profiles/r04_cnn_phase_cycles.txt.)  Software-pipelined by hand as before: the next
+            // cell's gradient / arg-max reads are in flight while this cell's 18 window values arrive in one round trip.
+            if (grp < PW) {
+                typedef const __attribute__((address_space(3))) char* lptr_t;
+                typedef const __attribute__((address_space(3))) float* lfp_t;
+                typedef const __attribute__((address_space(3))) uint8_t* lbp_t;
+                lfp_t gq = (lfp_t)(gbuf + co1 * PC + grp * PW);             // gbufb lies C1 * PC floats behind gbuf: an immediate offset
+                lbp_t aq = (lbp_t)(ambuf + grp * PW * C1 + co1);
+                lptr_t wq = (lptr_t)(xp + (c0g * CG) * XP_PLANE_B + 2 * grp * XP_RS);
+                float gv_n = gq[0] + gq[C1 * PC];
+                int am_n = aq[0];
 #pragma unroll 1
-            for (int c = grp; c < PC; c += NGRP) {
-                const float gv = gv_n;
-                const float* base = xp + (c0g * CG) * XP_PLANE_B + off_n;
-                float wv[CG * 9];
+                for (int cx = 0; cx < PW; ++cx) {
+                    const float gv = gv_n;
+                    const lfp_t base = (lfp_t)(wq + am_n);
+                    float wv[CG * 9];
 #pragma unroll
-                for (int j = 0; j < CG; ++j)
+                    for (int j = 0; j < CG; ++j)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) wv[j * 9 + ky * 3 + kx] = base[j * XP_PLANE_B + ky * XP_RS + kx];
-                cy += NGRP - PW; cx += 1;                               // e += 16 = 13 + 3
-                if (cy >= PW) { cy -= PW; cx += 1; }
-                if (c + NGRP < PC) cell_inputs(cy, cx, gv_n, off_n);
-                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);     // all DS reads of the round first ...
-                __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);     // ... then the VALU work
+                            for (int kx = 0; kx < 3; ++kx) wv[j * 9 + ky * 3 + kx] = base[j * XP_PLANE_B + ky * XP_RS + kx];
+                    gq += 1; aq += C1; wq += 8;
+                    if (cx + 1 < PW) { gv_n = gq[0] + gq[C1 * PC]; am_n = aq[0]; }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);     // all DS reads of the round first ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);     // ... then the VALU work
 #pragma unroll
-                for (int k = 0; k < CG * 9; ++k) aw1[k] = __builtin_fmaf(gv, wv[k], aw1[k]);
-                aw1[AW - 1] += gv;
+                    for (int k = 0; k < CG * 9; ++k) aw1[k] = __builtin_fmaf(gv, wv[k], aw1[k]);
+                    aw1[AW - 1] += gv;
+                }
             }
         }
 #endif
@@ -708,7 +714,7 @@ __global__ void __launch_bounds__(CNN_NT_BWD, CNN_BWD_WAVES) rs_cnn_bwd_kernel(C
                 const int y = r + ((st_pack >> 4) & 3) - 1, x = c + ((st_pack >> 6) & 3) - 1;
                 if (y >= 0 && y < 2 * PW && x >= 0 && x < 2 * PW) {
                     const int pcell = (y >> 1) * PW + (x >> 1);
-                    if (ambuf[pcell * C1 + st_co] == (((y & 1) << 1) | (x & 1))) gst += gbuf[st_co * PC + pcell] + gbufb[st_co * PC + pcell];
+                    if (ambuf[pcell * C1 + st_co] == (uint8_t)((y & 1) * (4 * XP_RS) + (x & 1) * 4)) gst += gbuf[st_co * PC + pcell] + gbufb[st_co * PC + pcell];
                 }
             }
         }
