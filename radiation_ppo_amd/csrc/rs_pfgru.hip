@@ -9,7 +9,7 @@
 // small matrix products (27 -> 48, 27 -> 48, 27 -> 1) are per-lane FMA chains whose weights are workgroup-uniform: they arrive
 // through the scalar unit (s_load_dwordx16 from the constant address space -> SGPR operand of v_fma, ordered wait -> request ->
 // FMA by rs_sstream.hpp), costing neither VGPRs nor LDS bandwidth.  Both gate products are consumed chunk by chunk (16 live
-// accumulators: 125-128 VGPRs, four waves per SIMD, no scratch).  A set's 40 lanes straddle waves, so what couples its particles --
+// accumulators, packed in pairs: 147-155 VGPRs, three waves per SIMD, no scratch).  A set's 40 lanes straddle waves, so what couples its particles --
 // two log-softmaxes, the float64 resampling CDF, the gather of resampled particles, the weighted mean, the hid_obs head -- goes
 // through LDS and workgroup barriers; every lane reads the set's 40 values back and reduces them in index order (deterministic,
 // independent of which sets share a workgroup).  Random draws (reparameterisation noise: one splitmix64 hash per PAIR of units ->
@@ -20,8 +20,9 @@
 // copies of the step with the particle set in registers in between (rs_pfgru_pass: the policy loop's 120-step passes in 30
 // launches); <true, 1> the same arithmetic with noise / resampling indices read from buffers (the reference's recorded runs).
 //
-// Bound: VALU issue.  Algorithmic work 2 619 multiply-adds per particle-step (2 x 27 x 48 + 27); the kernel issues ~2 700 FMAs +
-// 12 hashes + ~120 hardware transcendentals per lane and step.  16 384 sets x 40 particles at config 4: 98 us per step =
+// Bound: VALU issue.  Algorithmic work 2 619 multiply-adds per particle-step (2 x 27 x 48 + 27); the kernel issues 1 296 v_pk_fma_f32
+// (two multiply-adds each; a SIMD retires one per 4 cycles, a plain v_fma_f32 per 2: the same FLOP rate from half the instructions) +
+// 12 hashes + ~300 hardware transcendentals (8 cycles each) per lane and step.  16 384 sets x 40 particles at config 4: 98 us per step =
 // 35 TFLOP/s of algorithmic work = 0.22 of the 157.3 TFLOP/s f32 peak (bench.py: roofline_pfgru_step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -118,8 +119,13 @@ __device__ __forceinline__ float pk_sum40(const float* v) {          // index or
 // hipcc keeps a `#pragma unroll` loop over the steps a loop -- the schedule of the weight stream falls apart (412 B of scratch, 204 SGPR
 // spills).  Between the copies the weight pointer and the lane indices are laundered together with the log-weight
 // the previous copy produced, so that nothing of the next copy is requested, computed or kept early (without: 360 B of scratch).
+#ifndef RS_K11_OCC
+#define RS_K11_OCC 3        // waves per SIMD the register budget is cut for.  With the weight streams' accumulators as v_pk_fma_f32 pairs (rs_sstream.hpp)
+                            // 4 spills 20-72 registers (84-116 B of scratch); 3 = 147-155 VGPRs, none.  A/B on one box, RAD-A2C leg of bench.py
+                            // (gpurun_out/r4b_ab1.txt): scalar FMAs at 4: pass 12.8 ms, 1.45 M env steps/s; pairs at 4: 12.0 ms, 1.49 M; pairs at 3: 11.5 ms, 1.54 M
+#endif
 template <bool REC, int STEPS = 1>
-__global__ void __launch_bounds__(PK_NT, 4) rs_pfgru_kernel(PfArgs a_, int groups) {
+__global__ void __launch_bounds__(PK_NT, RS_K11_OCC) rs_pfgru_kernel(PfArgs a_, int groups) {
     __shared__ __align__(16) float smem[PK_SETS * PK_STRIDE];
     const int tid = threadIdx.x;
     const int own = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)groups));       // one owner per workgroup: wave-uniform weights

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 typedef const float __attribute__((address_space(4))) * rs_cmem_t;
+typedef float rs_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rs_cmem_t rs_as_cmem(const float* p) { return (rs_cmem_t)(uintptr_t)p; }
 
 #define RS_SS_ARRIVED(w) asm volatile("" :: "s"((w)[0]), "s"((w)[16]))
@@ -31,6 +32,12 @@ __device__ __forceinline__ void rs_ss_mv_cols(rs_cmem_t W, F cval, float (&acc)[
     constexpr int RPB = 32 / NC;                                     // rows per block: 2 or 4
     constexpr int NB = (K + RPB - 1) / RPB;                          // a short last block re-reads row K - 1 and skips its FMAs
     float wq[2][32];
+    // the accumulators as explicit pairs: v_pk_fma_f32 acc[2q : 2q+1] += s[w : w+1] * (c, c) takes the SGPR pair of two adjacent columns
+    // and the lane's value broadcast by op_sel -- two multiply-adds per issue slot.  (Left as scalar fmaf the chain compiled to one
+    // v_fmac_f32 per multiply-add: K11 - K15 issued 2 554 / 2 538 / 1 661 / 4 518 of them, half of all their instructions, round 4.)
+    rs_v2f a2[NC / 2];
+#pragma unroll
+    for (int q = 0; q < NC / 2; ++q) a2[q] = (rs_v2f){acc[2 * q], acc[2 * q + 1]};
 #pragma unroll
     for (int i = 0; i < 32; ++i) wq[0][i] = W[((i / NC) < K ? (i / NC) : K - 1) * STRIDE + C0 + (i % NC)];
 #pragma unroll
@@ -51,13 +58,16 @@ __device__ __forceinline__ void rs_ss_mv_cols(rs_cmem_t W, F cval, float (&acc)[
             if (RPB * b + r < K) {
                 const float c = cval(RPB * b + r);
 #pragma unroll
-                for (int o = 0; o < NC; ++o) acc[o] = fmaf(cur[r * NC + o], c, acc[o]);
+                for (int q = 0; q < NC / 2; ++q)
+                    a2[q] = __builtin_elementwise_fma((rs_v2f){cur[r * NC + 2 * q], cur[r * NC + 2 * q + 1]}, (rs_v2f){c, c}, a2[q]);
             }
         }
 #pragma unroll
-        for (int o = 0; o < NC; ++o) asm volatile("" : "+v"(acc[o]));
+        for (int q = 0; q < NC / 2; ++q) asm volatile("" : "+v"(a2[q]));
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int o = 0; o < NC; ++o) acc[o] = a2[o / 2][o & 1];
 }
 
 // out[0 .. OUTR) += W^T c for a k-major [K][OUTP] block (OUTP = the row stride, a multiple of 16; OUTR <= OUTP the columns that are
