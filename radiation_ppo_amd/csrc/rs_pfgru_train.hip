@@ -66,6 +66,7 @@ static_assert(G_END <= RS_PFGRU_TRAIN_GRAD_FLOATS, "include/radsearch.h: RS_PFGR
 typedef const float __attribute__((address_space(4))) * cmem_t;
 __device__ __forceinline__ cmem_t as_cmem(const float* p) { return (cmem_t)(uintptr_t)p; }
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float v2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float wave_max(float v) { return rs_wave_max(v); }     // csrc/rs_wave.hpp: DPP rows + v_readlane, no LDS
 __device__ __forceinline__ float wave_sum(float v) { return rs_wave_sum(v); }
@@ -79,6 +80,11 @@ template <int L>
 __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+// The backward walk's exponentials, logarithms and quotients on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each, as
+// K11's cell): the library expf / logf / IEEE division are 10-20 instructions each, ~200 of a step's 5 000 at the lone-wave issue rate
+__device__ __forceinline__ float bw_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504f * x); }
+__device__ __forceinline__ float bw_log(float x) { return 0.69314718f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float bw_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // gates and candidate state of one particle: z, r, n, es = eps * d softplus(var) / d var, h1 = (1 - z) n + z h0, lg = fc_obs([h1, x])
 // One step of the cell for the forward walk: h1 and the observation logit; the gates z | r | n | eps * softplus'(var) go straight to
@@ -152,8 +158,10 @@ struct TrArgs {
     float alpha, floor_, l2w, l1w, elbo;
 };
 
-constexpr int ROW = H + 1;                 // 25: odd stride
-constexpr int TILE_F = 44 * ROW;           // [44][25] particle rows (gather / scatter-add / column sums)
+constexpr int ROW = H + 1;                 // 25: odd stride (forward walk's particle rows)
+constexpr int BROW = 33;                   // backward walk: the matrix-core products hand back 2 x 3 tiles of 16 x 16 = 32 units x 48 particle
+constexpr int TILE_F = 48 * BROW;          // columns; [48][33] takes ALL of them, so their 24 stores per product need no predicate (with [44][25]
+                                           // each tile's stores sat behind an exec-mask save / branch / restore: ~120 scalar instructions per step)
 constexpr int SP = 45;                     // staging row stride: 44 particle columns + 1
 constexpr int DT_F = 48 * SP, IT_F = 32 * SP;
 constexpr int PRE_F = P * 4 * H;           // the next backward step's gates, fetched by LDS-DMA while the current step computes (15 KB)
@@ -273,13 +281,11 @@ __device__ __forceinline__ void mvt_mfma(const float (&wa)[2][KK], const float* 
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int pp = 16 * nt + c, u0 = 16 * mt + 4 * q;
-            if (u0 < H && pp < 44) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) tile[pp * ROW + u0 + v] = acc[mt][nt][v];
-            }
+            for (int v = 0; v < 4; ++v) tile[pp * BROW + u0 + v] = acc[mt][nt][v];
         }
     __builtin_amdgcn_wave_barrier();
-    const float* row = tile + (lane < 44 ? lane : 43) * ROW;
+    const float* row = tile + (lane < 48 ? lane : 47) * BROW;
 #pragma unroll
     for (int u = 0; u < H; ++u) out[u] = ACC ? out[u] + row[u] : row[u];
     __builtin_amdgcn_wave_barrier();
@@ -434,7 +440,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     __shared__ __align__(16) float smem[LDS_FLOATS];
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
-    float* tile = smem;                                              // [44][ROW]
+    float* tile = smem;                                              // [48][BROW]
     float* vec = smem + TILE_F + 2 * P;                              // [64]
     float* DT = vec + 64;                                            // [48][SP]
     float* IT = DT + DT_F;                                           // [32][SP]
@@ -493,7 +499,6 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     const float l2w = a_.l2w, l1w = a_.l1w, elbo = a_.elbo;
     float l2s = 0.0f, l1s = 0.0f, l2ps = 0.0f, l1ps = 0.0f;          // the episode's four loss terms (wave-uniform)
     const bool stage = lane < 44;                                    // the lanes that own a staging column
-    const bool act41 = lane <= P;                                    // particles + the mean "particle" in lane 40
 
     // a step's gates (40 x 96 floats, contiguous in HBM) -> `pre`, 15 global_load_lds_dwordx4: issued for step t - 1 as soon as step
     // t's gates are in registers, so the 15 KB arrive under the ~90 k cycles of the step instead of in front of it
@@ -561,21 +566,21 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         K13_STAMP(2)                                                 // backward: loads of the step's gates, h1 and logit
         lg += p0;
         const float mx = wave_max(act ? lg : -INFINITY);
-        const float se = wave_sum(act ? expf(lg - mx) : 0.0f);
-        const float p1 = (lg - mx) - logf(se);
-        const float pi = act ? expf(ps_t) : 0.0f;
+        const float se = wave_sum(act ? bw_exp(lg - mx) : 0.0f);
+        const float p1 = (lg - mx) - bw_log(se);
+        const float pi = act ? bw_exp(ps_t) : 0.0f;
 
         float wf[2][6];
         f4 bf[2];
         { const float* wg = wglob(); mv_fetch<6, 32>(wg + T_H0, wg + T_H0B, wf, bf, lane); }   // hid_obs[0]'s fragments: requested a phase ahead of their product
         // ---- weighted mean of the resampled particles -> vec[0..23]
 #pragma unroll
-        for (int u = 0; u < H; ++u) if (act) tile[lane * ROW + u] = pi * h1r[u];
+        for (int u = 0; u < H; ++u) if (act) tile[lane * BROW + u] = pi * h1r[u];
         __builtin_amdgcn_wave_barrier();
         {
             const int ul = lane < H ? lane : H - 1;
             float mean = 0.0f;
-            for (int q = 0; q < P; ++q) mean += tile[q * ROW + ul];
+            for (int q = 0; q < P; ++q) mean += tile[q * BROW + ul];
             __builtin_amdgcn_wave_barrier();
             vec[lane] = mean;
             __builtin_amdgcn_wave_barrier();
@@ -588,8 +593,8 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         // staged once for both the forward product below (matrix cores, as the transposed products) and hid_obs[0]'s weight gradient
         if (stage) {
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act41 ? v[k] : 0.0f;
-            IT[H * SP + lane] = act41 ? 1.0f : 0.0f;
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = v[k];        // columns 41..43 (finite: the mean): their DT columns are zero, see below
+            IT[H * SP + lane] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         float uu[H];
@@ -609,16 +614,16 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float d = out[c] - tr[c];
-            const float e2 = act ? expf(-d * d * bpt) : 0.0f;
+            const float e2 = act ? bw_exp(-d * d * bpt) : 0.0f;
             const float y2 = wave_sum(e2) * (1.0f / P);
-            float gpart = l2w * 2.0f * d * bpt * e2 / (P * y2);
-            l2ps += -logf(y2);
+            float gpart = bw_div(l2w * 2.0f * d * bpt * e2, P * y2);
+            l2ps += -bw_log(y2);
             if (l1w != 0.0f) {
-                const float e1 = act ? expf(-fabsf(d) * bpt) : 0.0f;
+                const float e1 = act ? bw_exp(-fabsf(d) * bpt) : 0.0f;
                 const float y1 = wave_sum(e1) * (1.0f / P);
                 const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-                gpart += l1w * 10.0f * sg * bpt * e1 / (P * y1);
-                l1ps += -logf(y1);
+                gpart += bw_div(l1w * 10.0f * sg * bpt * e1, P * y1);
+                l1ps += -bw_log(y1);
             }
             const float dm = lane_bcast<P>(d);                           // the mean prediction's error (lane 40)
             const float sgm = dm > 0.0f ? 1.0f : (dm < 0.0f ? -1.0f : 0.0f);
@@ -635,7 +640,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         for (int k = 0; k < H; ++k) du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
         if (stage) {
 #pragma unroll
-            for (int k = 0; k < H; ++k) DT[k * SP + lane] = act41 ? du[k] : 0.0f;        // IT still holds [v | 1]
+            for (int k = 0; k < H; ++k) DT[k * SP + lane] = du[k];        // zero in columns 41..43 by construction (dop is); IT still holds [v | 1]
         }
         __builtin_amdgcn_wave_barrier();
         float wh[2][6];
@@ -646,9 +651,9 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         // d hid_obs[2] = sum over particles (and the mean) of dop (x) [relu(u) | 1]: rows 0, 1 of a tile (rows 2..15 hold stale du: their
         // products land in accumulator rows that are never stored)
         if (stage) {
-            DT[0 * SP + lane] = act41 ? dop[0] : 0.0f; DT[1 * SP + lane] = act41 ? dop[1] : 0.0f;
+            DT[0 * SP + lane] = dop[0]; DT[1 * SP + lane] = dop[1];                     // dop = 0 beyond lane 40
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act41 ? uu[k] : 0.0f;      // row 24 still holds the ones
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = uu[k];      // row 24 still holds the ones
         }
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2>(DT, IT, accW2, lane);
@@ -667,8 +672,8 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         const float dpn = dp1r - pi * S;                             // through p1r = pn - logsumexp(pn)
         vec[lane] = p1;
         __builtin_amdgcn_wave_barrier();
-        const float wj = expf(vec[idx]);
-        const float gp = dpn * floor_ / (al * wj + floor_);          // through pn = log(w / (alpha w + floor))
+        const float wj = bw_exp(vec[idx]);
+        const float gp = bw_div(dpn * floor_, al * wj + floor_);          // through pn = log(w / (alpha w + floor))
         // ---- back through the gather: every source particle sums the gradients of the lanes that resampled it.  Not by LDS float atomics
         // (25 x ds_add_f32 per lane took ~360 cycles each: 9 000 of the step's 61 000 cycles): one INTEGER atomic per lane builds the list of
         // a source's takers, every lane stores its gradient row, and each source then pulls its takers' rows (reads only, no
@@ -679,8 +684,8 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             const int slot_ = __hip_atomic_fetch_add(&cnt[idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             takers[idx * P + slot_] = (unsigned char)lane;
 #pragma unroll
-            for (int k = 0; k < H; ++k) tile[lane * ROW + k] = dh[k];
-            tile[lane * ROW + H] = gp;
+            for (int k = 0; k < H; ++k) tile[lane * BROW + k] = dh[k];
+            tile[lane * BROW + H] = gp;
         }
         __builtin_amdgcn_wave_barrier();
         float dh1[H];
@@ -690,49 +695,61 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         const int ntk = act ? cnt[pl] : 0;
         for (int s_ = 0; __any(s_ < ntk); ++s_) {
             if (s_ < ntk) {
-                const float* row = tile + (int)takers[pl * P + s_] * ROW;
+                const float* row = tile + (int)takers[pl * P + s_] * BROW;
 #pragma unroll
                 for (int k = 0; k < H; ++k) dh1[k] += row[k];
                 dp1 += row[H];
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const float dlp = dp1 - expf(p1) * wave_sum(dp1);            // through p1 = lp - logsumexp(lp); also d / d p0
+        const float dlp = dp1 - bw_exp(p1) * wave_sum(dp1);            // through p1 = lp - logsumexp(lp); also d / d p0
         dp = dlp;
         K13_STAMP(6)                                                 // resampling backwards: scatter-add, softmax derivatives
         // ---- fc_obs: d fc_obs = sum over particles of dlp (x) [h1 | x | 1] (row 0 of a tile, as d hid_obs[2] above)
 #pragma unroll
         for (int k = 0; k < H; ++k) dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
         if (stage) {
-            DT[0 * SP + lane] = act ? dlp : 0.0f;
+            // (the three particle-only outer products below contract over columns 0..39 only -- KS = 10 -- and a transposed product's
+            // output column depends on its own input column alone: columns 40..43 carry whatever the shadow lanes hold, unselected.
+            // The selects that zeroed them were ~250 of the step's 5 200 instructions at the lone-wave issue rate.)
+            DT[0 * SP + lane] = dlp;
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? h1[k] : 0.0f;
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = h1[k];
 #pragma unroll
-            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = act ? x[k] : 0.0f;
-            IT[27 * SP + lane] = act ? 1.0f : 0.0f;
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = x[k];
+            IT[27 * SP + lane] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2, 10>(DT, IT, accO, lane);
         __builtin_amdgcn_wave_barrier();
         K13_STAMP(7)                                                 // fc_obs outer product
         // ---- h1 = (1 - z) n + z h0, n = tanh(mu + eps softplus(var))
+        // (element-wise chains as explicit pairs -- v_pk_mul_f32 / v_pk_add_f32: a lone wave issues one vector instruction per ~3.4 ns
+        // whatever it is, so a packed one is two for the price of one: profiles/r04_valu_cost.txt)
         float dan[48], dz[H];
 #pragma unroll
-        for (int u = 0; u < H; ++u) {
-            const float dn = dh1[u] * (1.0f - z[u]);
-            dz[u] = dh1[u] * (h0[u] - n[u]);
-            dh[u] = dh1[u] * z[u];                                   // dL / d h0 (direct path)
-            const float dm = dn * (1.0f - n[u] * n[u]);
-            dan[u] = dm; dan[H + u] = dm * es[u];
+        for (int u = 0; u < H; u += 2) {
+            const v2 z2 = {z[u], z[u + 1]}, n2 = {n[u], n[u + 1]}, g2 = {dh1[u], dh1[u + 1]}, h2 = {h0[u], h0[u + 1]}, e2 = {es[u], es[u + 1]};
+            const v2 one = {1.0f, 1.0f};
+            const v2 dn = g2 * (one - z2);
+            const v2 dz2 = g2 * (h2 - n2);
+            const v2 dh2 = g2 * z2;                                  // dL / d h0 (direct path)
+            const v2 dm = dn * (one - n2 * n2);
+            const v2 dv2 = dm * e2;
+            dz[u] = dz2.x; dz[u + 1] = dz2.y; dh[u] = dh2.x; dh[u + 1] = dh2.y;
+            dan[u] = dm.x; dan[u + 1] = dm.y; dan[H + u] = dv2.x; dan[H + u + 1] = dv2.y;
         }
         if (stage) {
 #pragma unroll
-            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = act ? dan[o] : 0.0f;
+            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = dan[o];
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? r[k] * h0[k] : 0.0f;
+            for (int k = 0; k < H; k += 2) {
+                const v2 t2 = (v2){r[k], r[k + 1]} * (v2){h0[k], h0[k + 1]};
+                IT[k * SP + lane] = t2.x; IT[(k + 1) * SP + lane] = t2.y;
+            }
 #pragma unroll
-            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = act ? x[k] : 0.0f;
-            IT[27 * SP + lane] = act ? 1.0f : 0.0f;
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = x[k];
+            IT[27 * SP + lane] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         float wa[2][12];
@@ -744,17 +761,21 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         K13_STAMP(9)                                                 // transposed product N
         // ---- z, r = sigmoid(W_zr [h0, x] + b)
 #pragma unroll
-        for (int u = 0; u < H; ++u) {
-            dh[u] = fmaf(drh[u], r[u], dh[u]);
-            const float dr = drh[u] * h0[u];
-            dan[u] = dz[u] * z[u] * (1.0f - z[u]);                    // dan now holds d (a_z | a_r)
-            dan[H + u] = dr * r[u] * (1.0f - r[u]);
+        for (int u = 0; u < H; u += 2) {
+            const v2 z2 = {z[u], z[u + 1]}, r2 = {r[u], r[u + 1]}, d2 = {drh[u], drh[u + 1]}, h2 = {h0[u], h0[u + 1]}, q2 = {dz[u], dz[u + 1]};
+            const v2 one = {1.0f, 1.0f};
+            const v2 dh2 = __builtin_elementwise_fma(d2, r2, (v2){dh[u], dh[u + 1]});
+            const v2 dr = d2 * h2;
+            const v2 az = q2 * z2 * (one - z2);                      // dan now holds d (a_z | a_r)
+            const v2 ar = dr * r2 * (one - r2);
+            dh[u] = dh2.x; dh[u + 1] = dh2.y;
+            dan[u] = az.x; dan[u + 1] = az.y; dan[H + u] = ar.x; dan[H + u + 1] = ar.y;
         }
         if (stage) {
 #pragma unroll
-            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = act ? dan[o] : 0.0f;
+            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = dan[o];
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = act ? h0[k] : 0.0f;      // rows 24..27 still hold x | 1
+            for (int k = 0; k < H; ++k) IT[k * SP + lane] = h0[k];      // rows 24..27 still hold x | 1
         }
         __builtin_amdgcn_wave_barrier();
         mvt_fetch<12, 48>(wglob() + T_ZR, wa, lane);
