@@ -498,16 +498,30 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
     const float inv_nel = 1.0f / (float)(2 * len);
     const float l2w = a_.l2w, l1w = a_.l1w, elbo = a_.elbo;
     float l2s = 0.0f, l1s = 0.0f, l2ps = 0.0f, l1ps = 0.0f;          // the episode's four loss terms (wave-uniform)
-    const bool stage = lane < 44;                                    // the lanes that own a staging column
+    // staging column of this lane: lanes 44..63 all write the rows' PAD column (44: read by nothing but the transposed products' dropped
+    // output columns), so no staging store sits behind an exec-mask save / restore
+    const int scol = lane < 44 ? lane : 44;
 
     // a step's gates (40 x 96 floats, contiguous in HBM) -> `pre`, 15 global_load_lds_dwordx4: issued for step t - 1 as soon as step
     // t's gates are in registers, so the 15 KB arrive under the ~90 k cycles of the step instead of in front of it
+    // Four base pairs (global, LDS) x up to four chunks selected by the instruction's immediate offset, which the hardware adds to BOTH
+    // addresses: 15 transfers + 8 address instructions.  (One generic -> LDS pointer conversion per transfer came with a null check and a
+    // 64-bit add each: ~90 scalar / vector instructions per step at the lone-wave issue rate.)
+    typedef __attribute__((address_space(3))) float* lds_f;
+    typedef const __attribute__((address_space(1))) float* glb_f;
+    const lds_f pre3 = (lds_f)pre;
     auto dma_gates = [&](int t) {
-        const float* src = a_.gates + ((size_t)t * E + e) * (size_t)(P * 4 * H);
+        const float* src = a_.gates + ((size_t)t * E + e) * (size_t)(P * 4 * H) + lane * 4;
+        static_assert(PRE_F / 256 == 15, "15 transfers of 256 floats");
 #pragma unroll
-        for (int i = 0; i < PRE_F / 256; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(pre + i * 256), 16, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+            const glb_f gp = (glb_f)(src + g * 1024);
+            const lds_f lp = pre3 + g * 1024;
+            __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+            if (g < 3) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+        }
     };
     if (len > 0) dma_gates(len - 1);
 
@@ -573,7 +587,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float wf[2][6];
         f4 bf[2];
         { const float* wg = wglob(); mv_fetch<6, 32>(wg + T_H0, wg + T_H0B, wf, bf, lane); }   // hid_obs[0]'s fragments: requested a phase ahead of their product
-        // ---- weighted mean of the resampled particles -> vec[0..23]
+        // ---- weighted mean of the resampled particles (unit u summed by lane u)
 #pragma unroll
         for (int u = 0; u < H; ++u) if (act) tile[lane * BROW + u] = pi * h1r[u];
         __builtin_amdgcn_wave_barrier();
@@ -582,20 +596,16 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             float mean = 0.0f;
             for (int q = 0; q < P; ++q) mean += tile[q * BROW + ul];
             __builtin_amdgcn_wave_barrier();
-            vec[lane] = mean;
-            __builtin_amdgcn_wave_barrier();
-        }
-        K13_STAMP(3)                                                 // log-softmax, loads of the resampled set, weighted mean
-        // ---- hid_obs on every particle (lanes 0..39) and on the mean (lane 40)
-        float v[H];
+            // staged once for both the forward product below (matrix cores, as the transposed products) and hid_obs[0]'s weight gradient:
+            // the particles' columns straight from their lanes, the mean's column (40) from the 24 lanes that summed it.  (Column 40 used to go
+            // lane 0..23 -> vec -> lane 40's registers -> IT: 24 LDS reads and 24 selects in every lane.)  Columns 41..43 hold the shadow
+            // lanes' particle (finite); their DT columns are zero, see below.
 #pragma unroll
-        for (int k = 0; k < H; ++k) v[k] = act ? h1r[k] : vec[k];
-        // staged once for both the forward product below (matrix cores, as the transposed products) and hid_obs[0]'s weight gradient
-        if (stage) {
-#pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = v[k];        // columns 41..43 (finite: the mean): their DT columns are zero, see below
-            IT[H * SP + lane] = 1.0f;
+            for (int k = 0; k < H; ++k) IT[k * SP + scol] = h1r[k];
+            IT[H * SP + scol] = 1.0f;
+            if (lane < H) IT[lane * SP + P] = mean;                  // (program order: after lane 40's own store to the same column)
         }
+        K13_STAMP(3)                                                 // log-softmax, loads of the resampled set, weighted mean; hid_obs staging
         __builtin_amdgcn_wave_barrier();
         float uu[H];
         mvt_mfma<6, false>(wf, IT, tile, lane, uu, bf[0], bf[1]);
@@ -638,9 +648,9 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         float du[H];
 #pragma unroll
         for (int k = 0; k < H; ++k) du[k] = uu[k] > 0.0f ? W[T_H2 + k] * dop[0] + W[T_H2 + H + k] * dop[1] : 0.0f;
-        if (stage) {
+        {
 #pragma unroll
-            for (int k = 0; k < H; ++k) DT[k * SP + lane] = du[k];        // zero in columns 41..43 by construction (dop is); IT still holds [v | 1]
+            for (int k = 0; k < H; ++k) DT[k * SP + scol] = du[k];        // zero in columns 41..43 by construction (dop is); IT still holds [v | 1]
         }
         __builtin_amdgcn_wave_barrier();
         float wh[2][6];
@@ -650,10 +660,10 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         mvt_mfma<6, false>(wh, DT, tile, lane, dv);                  // particles and (lane 40) the mean
         // d hid_obs[2] = sum over particles (and the mean) of dop (x) [relu(u) | 1]: rows 0, 1 of a tile (rows 2..15 hold stale du: their
         // products land in accumulator rows that are never stored)
-        if (stage) {
-            DT[0 * SP + lane] = dop[0]; DT[1 * SP + lane] = dop[1];                     // dop = 0 beyond lane 40
+        {
+            DT[0 * SP + scol] = dop[0]; DT[1 * SP + scol] = dop[1];                     // dop = 0 beyond lane 40
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = uu[k];      // row 24 still holds the ones
+            for (int k = 0; k < H; ++k) IT[k * SP + scol] = uu[k];      // row 24 still holds the ones
         }
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2>(DT, IT, accW2, lane);
@@ -708,16 +718,16 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
         // ---- fc_obs: d fc_obs = sum over particles of dlp (x) [h1 | x | 1] (row 0 of a tile, as d hid_obs[2] above)
 #pragma unroll
         for (int k = 0; k < H; ++k) dh1[k] = fmaf(dlp, W[T_O + k], dh1[k]);
-        if (stage) {
+        {
             // (the three particle-only outer products below contract over columns 0..39 only -- KS = 10 -- and a transposed product's
             // output column depends on its own input column alone: columns 40..43 carry whatever the shadow lanes hold, unselected.
             // The selects that zeroed them were ~250 of the step's 5 200 instructions at the lone-wave issue rate.)
-            DT[0 * SP + lane] = dlp;
+            DT[0 * SP + scol] = dlp;
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = h1[k];
+            for (int k = 0; k < H; ++k) IT[k * SP + scol] = h1[k];
 #pragma unroll
-            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = x[k];
-            IT[27 * SP + lane] = 1.0f;
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + scol] = x[k];
+            IT[27 * SP + scol] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         outer_acc<1, 2, 10>(DT, IT, accO, lane);
@@ -739,17 +749,17 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             dz[u] = dz2.x; dz[u + 1] = dz2.y; dh[u] = dh2.x; dh[u + 1] = dh2.y;
             dan[u] = dm.x; dan[u + 1] = dm.y; dan[H + u] = dv2.x; dan[H + u + 1] = dv2.y;
         }
-        if (stage) {
+        {
 #pragma unroll
-            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = dan[o];
+            for (int o = 0; o < 48; ++o) DT[o * SP + scol] = dan[o];
 #pragma unroll
             for (int k = 0; k < H; k += 2) {
                 const v2 t2 = (v2){r[k], r[k + 1]} * (v2){h0[k], h0[k + 1]};
-                IT[k * SP + lane] = t2.x; IT[(k + 1) * SP + lane] = t2.y;
+                IT[k * SP + scol] = t2.x; IT[(k + 1) * SP + scol] = t2.y;
             }
 #pragma unroll
-            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + lane] = x[k];
-            IT[27 * SP + lane] = 1.0f;
+            for (int k = 0; k < IN; ++k) IT[(H + k) * SP + scol] = x[k];
+            IT[27 * SP + scol] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         float wa[2][12];
@@ -771,11 +781,11 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
             dh[u] = dh2.x; dh[u + 1] = dh2.y;
             dan[u] = az.x; dan[u + 1] = az.y; dan[H + u] = ar.x; dan[H + u + 1] = ar.y;
         }
-        if (stage) {
+        {
 #pragma unroll
-            for (int o = 0; o < 48; ++o) DT[o * SP + lane] = dan[o];
+            for (int o = 0; o < 48; ++o) DT[o * SP + scol] = dan[o];
 #pragma unroll
-            for (int k = 0; k < H; ++k) IT[k * SP + lane] = h0[k];      // rows 24..27 still hold x | 1
+            for (int k = 0; k < H; ++k) IT[k * SP + scol] = h0[k];      // rows 24..27 still hold x | 1
         }
         __builtin_amdgcn_wave_barrier();
         mvt_fetch<12, 48>(wglob() + T_ZR, wa, lane);
