@@ -85,8 +85,8 @@ constexpr int PF_ROW = PF_H + 1;                                   // odd row st
 constexpr int PK_SETS = 6, PK_NT = 256;
 #ifndef RS_K11_PASS_STEPS
 #define RS_K11_PASS_STEPS 4        // time steps per launch of rs_pfgru_pass (1 .. 6).  A/B, 120-step pass of 16.5 k episodes inside the policy
-                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61, 5 = 12.76, 6 = 12.8 (127 VGPRs, 0 / 0 / 20 / .. B of scratch; the
-                                   // code of a copy is 44 KB; 8 copies do not compile: "illegal VGPR to SGPR copy")
+                                   // loop: 1 = 14.3 ms, 2 = 13.25, 3 = 12.89, 4 = 12.61, 5 = 12.76, 6 = 12.8 (scalar FMAs at 4 waves per SIMD, 127 VGPRs; with the
+                                   // packed pairs at 3 waves per SIMD 4 = 11.5 ms); the code of a copy is 35 KB; 8 copies do not compile: "illegal VGPR to SGPR copy")
 #endif
 // LDS of one set (floats): tile [40][25] | cdf 40 x f64 | va [40] | vb [40] | vc [40] | vm [24] (+ pad); the stride is 12 (mod 32) banks so
 // that the up to three sets a wave touches read different banks
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(PK_NT, RS_K11_OCC) rs_pfgru_kernel(PfArgs a_, 
             pk = k_eps * 1048583ull + (uint64_t)q * 4096ull;
         }
 
-        // ---- gates: z | r = sigmoid(W_zr [h0, x] + b), consumed chunk by chunk (16 accumulators live, not 48: the kernel fits 4 waves
-        // per SIMD that way): z stays, r becomes r * h0 at once
+        // ---- gates: z | r = sigmoid(W_zr [h0, x] + b), consumed chunk by chunk (16 accumulators = 8 pairs live, not 48: the kernel
+        // fits 3 waves per SIMD without spilling that way): z stays, r becomes r * h0 at once
         float z[PF_H], rh[PF_H];
         auto cv1 = [&](int k) -> float { return (k < PF_H) ? h0[k < PF_H ? k : 0] : x[(k >= PF_H && k < PF_K) ? k - PF_H : 0]; };
         {
