@@ -56,6 +56,10 @@ __device__ __forceinline__ uint64_t pf_hash(uint64_t key) {
 
 // sigmoid on the hardware transcendentals: v_exp_f32, v_rcp_f32 (1 ulp each)
 __device__ __forceinline__ float pf_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); }
+// the softmax / soft-resampling exponentials, logarithms and the one f32 quotient on the hardware transcendentals too (1 ulp each; the
+// library expf / logf / IEEE division were ~110 instructions per lane and step).  The float64 CDF quotient stays IEEE: it decides indices.
+__device__ __forceinline__ float pf_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504f * x); }
+__device__ __forceinline__ float pf_log(float x) { return 0.69314718f * __builtin_amdgcn_logf(x); }
 
 struct PfArgs {
     const float* w;           // [A][PF_STRIDE]
@@ -262,14 +266,14 @@ __global__ void __launch_bounds__(PK_NT, RS_K11_OCC) rs_pfgru_kernel(PfArgs a_, 
         if (act) va[q] = lg;
         __syncthreads();                                                // 1
         const float mx = pk_max40(va);
-        const float e1 = expf(lg - mx);
+        const float e1 = pf_exp(lg - mx);
         if (act) vb[q] = e1;
         __syncthreads();                                                // 2
-        float p1 = (lg - mx) - logf(pk_sum40(vb));
+        float p1 = (lg - mx) - pf_log(pk_sum40(vb));
         // ---- soft resampling: indices by inverse CDF of alpha * w + (1 - alpha) / P
         const float al = a_.alpha, floor_ = a_.floor_;
         if (act) {
-            va[q] = al * expf(p1) + floor_;
+            va[q] = al * pf_exp(p1) + floor_;
             vc[q] = p1;
 #pragma unroll
             for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = h1[u];
@@ -301,15 +305,15 @@ __global__ void __launch_bounds__(PK_NT, RS_K11_OCC) rs_pfgru_kernel(PfArgs a_, 
         }
 #pragma unroll
         for (int u = 0; u < PF_H; ++u) h1[u] = tile[idx * PF_ROW + u];
-        float pn = expf(vc[idx]);
-        pn = logf(pn / (al * pn + floor_));
+        float pn = pf_exp(vc[idx]);
+        pn = pf_log(pn * __builtin_amdgcn_rcpf(al * pn + floor_));
         if (act) vb[q] = pn;
         __syncthreads();                                                // 5
         const float mx2 = pk_max40(vb);
-        const float e2 = expf(pn - mx2);
+        const float e2 = pf_exp(pn - mx2);
         if (act) va[q] = e2;
         __syncthreads();                                                // 6
-        p1 = pn - (logf(pk_sum40(va)) + mx2);
+        p1 = pn - (pf_log(pk_sum40(va)) + mx2);
         if (s_ == STEPS - 1 && a_.carry && live) {
             float4* hw = reinterpret_cast<float4*>(a_.h + slot * PF_P * PF_H) + q;
 #pragma unroll
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(PK_NT, RS_K11_OCC) rs_pfgru_kernel(PfArgs a_, 
             a_.p[slot * PF_P + q] = p1;
         }
         // ---- weighted mean of the particles, then hid_obs: Linear(24, 24)-ReLU-Linear(24, 2)-ReLU
-        const float wgt = expf(p1);
+        const float wgt = pf_exp(p1);
         if (act) {
 #pragma unroll
             for (int u = 0; u < PF_H; ++u) tile[q * PF_ROW + u] = wgt * h1[u];      // every lane gathered its row before barrier 5

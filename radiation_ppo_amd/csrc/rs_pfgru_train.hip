@@ -80,7 +80,7 @@ template <int L>
 __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
-// The backward walk's exponentials, logarithms and quotients on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each, as
+// Both walks' exponentials, logarithms and f32 quotients on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each, as
 // K11's cell): the library expf / logf / IEEE division are 10-20 instructions each, ~200 of a step's 5 000 at the lone-wave issue rate
 __device__ __forceinline__ float bw_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504f * x); }
 __device__ __forceinline__ float bw_log(float x) { return 0.69314718f * __builtin_amdgcn_logf(x); }
@@ -377,12 +377,12 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
         if (act) va[q] = lg;
         __syncthreads();                                             // 1
         const float mx = fw_max40(va);
-        const float e1 = expf(lg - mx);
+        const float e1 = bw_exp(lg - mx);
         if (act) vb[q] = e1;
         __syncthreads();                                             // 2
-        const float p1 = (lg - mx) - logf(fw_sum40(vb));
+        const float p1 = (lg - mx) - bw_log(fw_sum40(vb));
         if (act) {
-            va[q] = al * expf(p1) + floor_;
+            va[q] = al * bw_exp(p1) + floor_;
             vc[q] = p1;
 #pragma unroll
             for (int u = 0; u < H; ++u) tile[q * ROW + u] = h1[u];
@@ -414,15 +414,15 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
         }
 #pragma unroll
         for (int u = 0; u < H; ++u) h0[u] = tile[idx * ROW + u];
-        float pn = expf(vc[idx]);
-        pn = logf(pn / (al * pn + floor_));
+        float pn = bw_exp(vc[idx]);
+        pn = bw_log(bw_div(pn, al * pn + floor_));
         if (act) vb[q] = pn;
         __syncthreads();                                             // 5
         const float mx2 = fw_max40(vb);
-        const float e2 = expf(pn - mx2);
+        const float e2 = bw_exp(pn - mx2);
         if (act) va[q] = e2;
         __syncthreads();                                             // 6
-        p0 = pn - (logf(fw_sum40(va)) + mx2);
+        p0 = pn - (bw_log(fw_sum40(va)) + mx2);
         if (on) {
             float4* hw = reinterpret_cast<float4*>(a_.hs + te * PH) + q;          // quad-major, as the gates: quad j of all particles contiguous
 #pragma unroll
