@@ -62,13 +62,25 @@ KERNEL2(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0
 KERNEL2(k_mov64, "v_mov_b64 %0, %4\n v_mov_b64 %1, %4\n v_mov_b64 %2, %4\n v_mov_b64 %3, %4\n")
 KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n")
 
+#define KERNEL2V(name, body)                                                                                \
+    __global__ void __launch_bounds__(256) name(float* out, int iters) {                                    \
+        typedef float v2f __attribute__((ext_vector_type(2)));                                              \
+        v2f a0 = {(float)threadIdx.x, 1.f}, a1 = {1.f, 2.f}, a2 = {2.f, 3.f}, a3 = {3.f, 4.f};               \
+        v2f b0 = {0.5f, 0.25f};                                                                             \
+        for (int it = 0; it < iters; ++it) {                                                                \
+            asm volatile(REP4(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "memory");        \
+        }                                                                                                   \
+        out[blockIdx.x * 256 + threadIdx.x] = a0.x + a1.x + a2.x + a3.x + a0.y + a1.y + a2.y + a3.y;        \
+    }
+KERNEL2V(k_pk_s16, "v_pk_fma_f32 %0, s[4:5], %4, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, s[6:7], %4, %1 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, s[8:9], %4, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, s[10:11], %4, %3 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %0, s[12:13], %4, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, s[14:15], %4, %1 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, s[16:17], %4, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, s[18:19], %4, %3 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %0, s[20:21], %4, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, s[22:23], %4, %1 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, s[24:25], %4, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, s[26:27], %4, %3 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %0, s[28:29], %4, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, s[30:31], %4, %1 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, s[32:33], %4, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, s[34:35], %4, %3 op_sel_hi:[1,0,1]\n ")
+
 struct Case { const char* name; void (*k)(float*, int); int per_trip; };
 
 int main() {
     float* out; hipMalloc(&out, 256 * 4 * 4 * 256 * sizeof(float));
     std::vector<Case> cases = {
         {"v_fma_f32 (VGPR operands)", k_fma, 32}, {"v_fmac_f32 with an SGPR operand", k_fmac_s, 32}, {"v_pk_fma_f32 (VGPR pairs)", k_pk_v, 64},
-        {"v_pk_fma_f32 (SGPR pair x splat)", k_pk_s, 64}, {"v_pk_add_f32", k_pk_add, 64}, {"v_add_u32", k_add_u32, 32}, {"v_mov_b32", k_mov, 32}, {"v_mov_b64", k_mov64, 64},
+        {"v_pk_fma_f32 (SGPR pair x splat)", k_pk_s, 64}, {"v_pk_fma_f32 (16 different SGPR pairs x splat)", k_pk_s16, 64}, {"v_pk_add_f32", k_pk_add, 64}, {"v_add_u32", k_add_u32, 32}, {"v_mov_b32", k_mov, 32}, {"v_mov_b64", k_mov64, 64},
         {"v_max_f32", k_max, 32}, {"v_cndmask_b32 (vcc)", k_cndmask, 32}, {"v_cndmask_b32 (SGPR pair mask)", k_cndmask_s, 32}, {"v_cmp_lt_f32 -> vcc", k_cmp, 32},
         {"v_lshl_add_u64", k_lshl_add_u64, 64}, {"v_mul_lo_u32", k_mul_lo, 32}, {"v_exp_f32", k_exp, 32}, {"v_readlane_b32", k_readlane, 32}, {"v_writelane_b32", k_writelane, 32},
         {"v_cndmask(vcc) / v_fma alternating", k_cnd_fma, 32}, {"v_cmp -> vcc, v_cndmask(vcc) pairs", k_cmp_cnd, 32}, {"v_cmp -> s[a:b], v_cndmask(s[a:b]) pairs", k_cmp64_cnd, 32}, {"v_cndmask(vcc), dst = src0", k_cnd_dep, 32}, {"v_ashrrev_i32 / v_and_b32", k_ashr_and, 32}, {"v_add_f32", k_add_f32, 32}, {"v_mul_f32", k_mul_f32, 32}, {"v_rcp_f32", k_rcp, 32}, {"s_nop 0", k_snop, 32}, {"s_add_u32", k_salu, 32}};
