@@ -194,10 +194,10 @@ int rs_rollout(rs_handle* h, const rs_mlp_params* actor, const rs_mlp_params* cr
     if (args->steps_per_epoch < 1 || args->steps_per_episode < 1) return RS_ERR_INVALID_ARG;
     size_t lds = sizeof(float) * (size_t)(rs_mlp16_lds_floats(8) + rs_mlp16_lds_floats(1)) + 16;
     lds += (has_obs ? (2 * RS_MAX_VERT * RS_WAVE * 4 + RS_MAX_VERT * RS_WAVE * 8) : 0);
-    lds += RS_WAVE * RS_OBS_DIM * 4 + RS_WAVE * 4 + 2 * RS_WAVE;
+    lds += RS_WAVE * RS_OBS_DIM * 4 + RS_WAVE * 4 + 2 * RS_WAVE + rs_rollout16_mailbox_bytes();
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (has_obs) hipLaunchKernelGGL(rs_rollout16_kernel<true>, dim3(P.N / 16), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
-    else hipLaunchKernelGGL(rs_rollout16_kernel<false>, dim3(P.N / 16), dim3(RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    if (has_obs) hipLaunchKernelGGL(rs_rollout16_kernel<true>, dim3(P.N / 16), dim3(2 * RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
+    else hipLaunchKernelGGL(rs_rollout16_kernel<false>, dim3(P.N / 16), dim3(2 * RS_WAVE), lds, s, P, to_dev(actor), to_dev(critic), *args);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
 }
 

@@ -11,6 +11,13 @@
 //   D lane l, reg q: sample l&15, unit 16it + 4*(l>>4) + q
 // so the k-step (ut, q) of the next layer consumes unit 16ut + 4g + q straight from the accumulator registers
 // (the 16x16 analogue of the kappa trick in rs_mlp.hpp).
+//
+// Two waves per workgroup (round 4).  A lone wave issues one instruction per ~3.4 ns whatever it is (profiles/r04_valu_cost.txt), and
+// a lock-step was one serial stream of ~2 900 of them although only  observation -> actor -> draw -> env step -> observation  is a
+// dependence chain: the critic's value is stored, never fed back.  Wave 0 walks the chain; wave 1 (another SIMD of the same CU, idle
+// before) evaluates the critic on the observations wave 0 leaves in an LDS mailbox -- the pre-reset one for the bootstrap value, the
+// post-reset one for the envs that were cut -- and writes val / last_val itself.  One workgroup barrier per lock-step, mailbox double
+// buffered (wave 0 runs a step ahead).  With the critic skipped outright the lock-step took 7.6 instead of 9.6 us: that is the bound.
 #pragma once
 #include "rs_mlp.hpp"
 
@@ -101,8 +108,11 @@ __device__ __forceinline__ void rs_bcast_x16(const float (&xo)[RS_IN_PAD], float
     for (int k = 0; k < RS_IN_PAD; ++k) xs[k] = __shfl(xo[k], src);
 }
 
+constexpr int RS_MB_PRE = 0, RS_MB_POST = 16 * RS_IN_PAD, RS_MB_FLAGS = 2 * 16 * RS_IN_PAD, RS_MB_SLOT = 2 * 16 * RS_IN_PAD + 16;   // words
+__host__ __device__ constexpr int rs_rollout16_mailbox_bytes() { return 2 * RS_MB_SLOT * 4; }
+
 template <bool HAS_OBS>
-__global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParams pa, RsMlpParams pc, rs_rollout_args R) {
+__global__ void __launch_bounds__(128) rs_rollout16_kernel(RsParams P, RsMlpParams pa, RsMlpParams pc, rs_rollout_args R) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* wts = reinterpret_cast<float*>(smem);
     unsigned char* p = smem + sizeof(float) * (size_t)(rs_mlp16_lds_floats(8) + rs_mlp16_lds_floats(1));
@@ -114,25 +124,55 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     float* lds_rew = tile + RS_WAVE * RS_OBS_DIM;
     uint8_t* lds_done = reinterpret_cast<uint8_t*>(lds_rew + RS_WAVE);
     uint8_t* lds_oob = lds_done + RS_WAVE;
+    float* mbox = reinterpret_cast<float*>(lds_oob + RS_WAVE);          // [2 slots][pre 16 x 12 | post 16 x 12 | flags 16]
 
     RsMlp16<8> ACT; RsMlp16<1> CRT;
     ACT.carve(wts);
     CRT.carve(wts + rs_mlp16_lds_floats(8));
     ACT.fill(pa); CRT.fill(pc);
 
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, j = lane & 15;
-    const bool own = lane < 16;                                   // lane (j, 0) owns env slot j
+    const bool own = lane < 16;                                   // lane (j, 0) of either wave stands for env slot j
     const int n = blockIdx.x * 16 + j;                            // N % 16 == 0 (checked by the host)
     const int N = P.N, T = R.steps_per_epoch, L = R.steps_per_episode;
     // obstacles: the four lanes (j, 0..3) of an env run its step together (rs_env_step_lane<true, 4>): lane (j, g) takes
     // corner g of every rectangle in the shortest-path loop, every 4th rectangle, two of the eight probe directions
     const int cj = lane >> 4;
     RsGeo g{lds_geo, 0, 0, 0};
-    if (HAS_OBS) {
+    if (HAS_OBS && wave == 0) {
         rs_load_geo(P, n, own, lds_geo, g);
         g.off = __shfl(g.off, j); g.stride = __shfl(g.stride, j); g.n = __shfl(g.n, j);
     }
     __syncthreads();
+
+    if (wave == 1) {
+        // ---- the critic's wave: message t (t = -1: the epoch's first observation) is written by wave 0 before barrier t
+        for (int t = -1; t < T; ++t) {
+            __syncthreads();
+            const float* M = mbox + (t & 1) * RS_MB_SLOT;
+            float xs[RS_IN_PAD];
+#pragma unroll
+            for (int k = 0; k < RS_IN_PAD; ++k) xs[k] = M[RS_MB_PRE + j * RS_IN_PAD + k];
+            float vb;
+            { float vv[1]; CRT.forward(xs, vv); vb = vv[0]; }
+            const int fl = reinterpret_cast<const int*>(M + RS_MB_FLAGS)[j];          // bit 0: cut, bit 1: boot (both 0 in message -1)
+            const bool cut = (fl & 1) != 0, boot = (fl & 2) != 0;
+            float v = vb;
+            if (__ballot(cut) != 0ull) {                          // the envs that were cut start again from the observation after the reset
+#pragma unroll
+                for (int k = 0; k < RS_IN_PAD; ++k) xs[k] = M[RS_MB_POST + j * RS_IN_PAD + k];
+                float vv[1];
+                CRT.forward(xs, vv);
+                v = cut ? vv[0] : vb;
+            }
+            if (own) {
+                if (t >= 0) R.last_val[(size_t)t * N + n] = (cut && boot) ? vb : 0.0f;
+                if (t + 1 < T) R.val[(size_t)(t + 1) * N + n] = v;
+            }
+        }
+        return;
+    }
 
     float oraw[RS_OBS_DIM];
 #pragma unroll
@@ -155,8 +195,15 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
     xo[0] = W.standardize(oraw[0]);
     xo[11] = 1.0f;                                                // constant input carrying the layer-1 bias
     rs_bcast_x16(xo, xs);
-    float v;
-    { float vv[1]; CRT.forward(xs, vv); v = vv[0]; }
+    {   // message -1: the epoch's first observation (no flags)
+        float* M = mbox + RS_MB_SLOT;
+        if (own) {
+#pragma unroll
+            for (int k = 0; k < RS_IN_PAD; ++k) M[RS_MB_PRE + j * RS_IN_PAD + k] = xo[k];
+            reinterpret_cast<int*>(M + RS_MB_FLAGS)[j] = 0;
+        }
+    }
+    __syncthreads();
 
     RsOut O;
     O.obs_row = tile + j * RS_OBS_DIM;
@@ -168,6 +215,7 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
 
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * N + n;
+        float* M = mbox + (t & 1) * RS_MB_SLOT;
         float lg[8];
         ACT.forward(xs, lg);
         int a = 0;
@@ -195,20 +243,17 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
 #pragma unroll
             for (int k = 0; k < RS_OBS_DIM; ++k) tile[lane * RS_OBS_DIM + k] = xo[k];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                         // (one wave: its LDS operations are ordered; this only pins the compiler)
         {
             float* dst = R.obs + ((size_t)t * N + (size_t)blockIdx.x * 16) * RS_OBS_DIM;
             for (int i = lane; i < 16 * RS_OBS_DIM; i += RS_WAVE) dst[i] = tile[i];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         bool cut = false;
-        float vb_own_dummy = 0.0f;
-        (void)vb_own_dummy;
         bool over = false, boot = false, ended = t == T - 1;
         if (own) {
             R.act[row] = (int64_t)a;
             R.logp[row] = logp;
-            R.val[row] = v;
             R.source_tar[row * 2 + 0] = srcx;
             R.source_tar[row * 2 + 1] = srcy;
         }
@@ -237,13 +282,11 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
 #pragma unroll
             for (int k = 1; k < RS_OBS_DIM; ++k) xo[k] = oraw[k];
             xo[0] = W.standardize(oraw[0]);
-        }
-        rs_bcast_x16(xo, xs);
-        float vb;
-        { float vv[1]; CRT.forward(xs, vv); vb = vv[0]; }
-        if (own) {
+            // the critic's message: the observation the bootstrap value is taken on, and whether it is
+#pragma unroll
+            for (int k = 0; k < RS_IN_PAD; ++k) M[RS_MB_PRE + j * RS_IN_PAD + k] = xo[k];
+            reinterpret_cast<int*>(M + RS_MB_FLAGS)[j] = (cut ? 1 : 0) | (boot ? 2 : 0);
             R.cut[row] = cut ? 1 : 0;
-            R.last_val[row] = (cut && boot) ? vb : 0.0f;
             if (over) {
                 ep_ret_sum += (double)ep_ret; ep_len_sum += (double)steps; ep_count += 1;
                 ep_ret_sq += (double)ep_ret * (double)ep_ret;
@@ -272,15 +315,12 @@ __global__ void __launch_bounds__(64) rs_rollout16_kernel(RsParams P, RsMlpParam
                 ep_ret = 0.0f;
                 ep_key = P.episode[n] - 1u; t_key = P.tstep[n];  // new episode: new source, new Philox counters
                 srcx = (float)P.src_x[n]; srcy = (float)P.src_y[n];
+#pragma unroll
+                for (int k = 0; k < RS_IN_PAD; ++k) M[RS_MB_POST + j * RS_IN_PAD + k] = xo[k];
             }
         }
-        v = vb;
-        if (__ballot(cut) != 0ull) {
-            rs_bcast_x16(xo, xs);
-            float vv[1];
-            CRT.forward(xs, vv);
-            v = cut ? vv[0] : vb;
-        }
+        rs_bcast_x16(xo, xs);
+        __syncthreads();                                          // message t is complete; wave 1 takes it from here
     }
     if (own) {
 #pragma unroll
