@@ -468,7 +468,9 @@ def run_config_a2c(dev, iters: int = 2, warmup: int = 1, cpu: bool = True):
     # as the GPU saw them (events on the side stream: ~13.7 ms each; a policy iteration cannot be shorter than its pass)
     kp = _ms(ev.get("rs_pfgru_pass", []))
     out["update_split_ms"] = {"k13_passes": sum(_ms(ev.get("rs_pfgru_train", []))) / iters, "policy_loop_wall": sum(loops) / max(len(loops), 1),
-                              "k11_pass_gpu_mean": (sum(kp) / len(kp)) if kp else None, "k11_passes_per_update": len(kp) / iters}
+                              # (a pass call covers one policy iteration or, batched, several: per iteration = total / iterations)
+                              "k11_pass_gpu_mean": (sum(kp) / max(sum(stops), 1)) if kp else None, "k11_passes_per_update": sum(stops) / iters,
+                              "k11_pass_calls_per_update": len(kp) / iters}
     ds = _ms(ev.get("rs_pfgru_train", []))
     if ds:
         # K13: 9 561 multiply-adds per particle-step (forward cell 2 619, hid_obs forward + backward 1 248, transposed products 2 328,

@@ -778,23 +778,41 @@ class RNNAgentPPO:
         cell.eval()
         return float(last.item()) if torch.is_tensor(last) else last             # one host read, after the loop
 
-    def loc_prefetch(self, B: EpisodeBatch, it: int):
-        """The no-grad PFGRU passes of policy iteration `it` (K11, every chunk) enqueued on a side stream: they depend on the batch and
-        on the PFGRU's weights only -- not on the policy being updated -- so iteration it + 1's passes (VALU bound, the whole chip)
-        run under iteration it's GRU recurrence (66 waves, latency bound), its head / loss kernels and the Adam step.
-        Returns ([loc per chunk], event)."""
+    def loc_prefetch(self, B: EpisodeBatch, its):
+        """The no-grad PFGRU passes of the policy iterations `its` (an int or a list; K11, every chunk) enqueued on a side stream: they
+        depend on the batch and on the PFGRU's weights only -- not on the policy being updated -- so the coming iterations' passes (VALU
+        bound, the whole chip) run under the current iteration's GRU recurrence (latency bound), its head / loss kernels and the Adam step.
+        Several iterations' passes go out as ONE pass over K x E particle sets (episode e's K copies adjacent, so the sets still running at
+        step t stay a prefix): a pass is 30 launches of ~2 750 workgroups on 768 resident slots, and the last, partly filled round of every
+        launch costs 6-8 % of it (scripts/time_k11_pass.py: 9.26 / 8.72 / 8.62 / 8.55 ms per 16 500 episodes at K = 1 / 2 / 3 / 4).
+        Returns ({iteration: [loc per chunk]}, event)."""
+        its = [its] if isinstance(its, int) else list(its)
+        K = len(its)
         self._side = side_stream(self.device)
         main = torch.cuda.current_stream(self.device)
-        if it == 0:
+        if its[0] == 0:
             self._side.wait_stream(main)                                     # the batch and update_model's weights are final
-        out = []
+        out = {it: [] for it in its}
         E = B.lens.shape[0]
         with torch.cuda.stream(self._side), torch.no_grad():
             for lo in range(0, E, self.episode_chunk):
                 Bc = B.chunk(slice(lo, min(lo + self.episode_chunk, E)))
-                loc = self._pfgru_pass_hip(Bc.X, HashDraws(Bc.key * 64 + 17 + it), Bc.lens_host)      # (fused_pfgru only: see update_agent)
+                if K == 1:
+                    loc = self._pfgru_pass_hip(Bc.X, HashDraws(Bc.key * 64 + 17 + its[0]), Bc.lens_host)      # (fused_pfgru only: see update_agent)
+                    loc.record_stream(main)
+                    out[its[0]].append(loc)
+                    continue
+                cache = B.__dict__.setdefault("_xrep", {})
+                ck = (lo, K)
+                if ck not in cache:                                              # the K-fold batch is the same for every group of the update
+                    cache[ck] = (Bc.X.repeat_interleave(K, dim=1).contiguous(),
+                                 None if Bc.lens_host is None else [l for l in Bc.lens_host for _ in range(K)])
+                Xr, lens_r = cache[ck]
+                keys = torch.stack([Bc.key * 64 + 17 + it for it in its], dim=1).reshape(-1)
+                loc = self._pfgru_pass_hip(Xr, HashDraws(keys), lens_r).view(Bc.X.shape[0], -1, K, 2)
                 loc.record_stream(main)
-                out.append(loc)
+                for k, it in enumerate(its):
+                    out[it].append(loc[:, :, k])
             ev = torch.cuda.Event()
             ev.record(self._side)
         return out, ev
@@ -886,15 +904,23 @@ class RNNAgentPPO:
         self.pi_optimizer.zero_grad(set_to_none=True)
         kk, term, s = 0, False, None
         ahead = self.device.type == "cuda" and self.agent.fused_pfgru and getattr(self, "use_prefetch", True)
-        nxt = self.loc_prefetch(B, 0) if ahead else None
+        # the passes are prefetched one group ahead: iteration 0 alone (its chain starts at once), then `pass_batch` iterations per pass
+        K = max(1, int(getattr(self, "pass_batch", 2)))        # A/B on one box, ms per iteration: 2: 1201, 3: 1205, 4: 1195-1203, 5: 1202, 8: 1221 (1: 1223)
+        groups = [[0]] + [list(range(i, min(i + K, self.train_pi_iters))) for i in range(1, self.train_pi_iters, K)]
+        queue = []
+        if ahead:
+            queue.append(self.loc_prefetch(B, groups.pop(0)))
+            if groups:
+                queue.append(self.loc_prefetch(B, groups.pop(0)))
+        cur = None
         t_loop = time.perf_counter()
         while not term and kk < self.train_pi_iters:
-            cur = nxt
-            if ahead:
-                # iteration kk + 1's PFGRU passes go to the side stream before iteration kk's own work is enqueued
-                nxt = self.loc_prefetch(B, kk + 1) if kk + 1 < self.train_pi_iters else None
+            if ahead and (cur is None or kk not in cur[0]):
+                cur = queue.pop(0)
+                if groups:                                                       # the group after this one goes to the side stream before this iteration's own work
+                    queue.append(self.loc_prefetch(B, groups.pop(0)))
                 torch.cuda.current_stream(self.device).wait_event(cur[1])
-            s, term = self.update_rada2c(B, kk, locs=cur[0] if ahead else None)
+            s, term = self.update_rada2c(B, kk, locs=cur[0][kk] if ahead else None)
             kk += 1
         self.policy_loop_seconds = time.perf_counter() - t_loop              # wall time of the loop (every iteration ends in a host read)
         if ahead:
