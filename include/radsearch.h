@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 3
+#define RS_ABI_VERSION 4
 #define RS_OBS_DIM 11      /* [measurement, x/scale, y/scale, 8 range sensors]  rad_search_env.py:589-593 */
 #define RS_NUM_ACTIONS 9   /* 0..7 directions, 8 idle                           rad_search_env.py:55-68  */
 #define RS_MAX_AGENTS 8
@@ -374,6 +374,13 @@ int rs_pfgru_train(const float* weights, const float* obs, const float* target, 
                    const float* h0, const float* eps, const double* u, float* hs, float* ps, float* gates, int32_t* idx, float* loss,
                    float* grads, int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
                    rs_stream_t stream);
+/* The same pass with the draws of rs_pfgru_draws(keys, ...) evaluated INSIDE the forward walk instead of read from h0 / eps / u: same keys,
+ * same counter hash, same arithmetic -- bit-identical loss, gradients and indices -- without the 104 bytes per particle-step the draws
+ * launch writes and the walk reads back (8.2 GB per pass at 16 500 episodes; ABI version 4).  h0 [E][40][24]: scratch (the forward walk
+ * leaves the initial particles there for the backward walk's last step). */
+int rs_pfgru_train_keyed(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
+                         const int64_t* keys, float* h0, float* hs, float* ps, float* gates, int32_t* idx, float* loss, float* grads, int32_t steps,
+                         int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight, rs_stream_t stream);
 
 /* ---- RAD-A2C GRU recurrence -----------------------------------------------------------------
  * The time loop of torch.nn.GRU(13, 24, 1) as SeqPt.forward / grad_step run it over whole episodes

@@ -112,6 +112,7 @@ SYMBOLS = [
                                  C.c_void_p]),
     ("rs_pfgru_draws", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rs_pfgru_train", C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    ("rs_pfgru_train_keyed", C.c_int, [C.c_void_p] * 14 + [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("rs_rnn_policy_step", C.c_int, [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]),
     ("rs_rnn_policy_step_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -175,7 +176,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rs_abi_version() != 3:
+    if lib.rs_abi_version() != 4:
         raise RuntimeError("librs_hip.so ABI version mismatch")
     _lib = lib
     return lib

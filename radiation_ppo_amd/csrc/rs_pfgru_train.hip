@@ -80,6 +80,13 @@ template <int L>
 __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+// splitmix64 finaliser on wrapping 64-bit arithmetic == pfgru.py: hash_bits == csrc/rs_pfgru.hip: pf_hash
+__device__ __forceinline__ uint64_t tr_hash(uint64_t key) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 // Both walks' exponentials, logarithms and f32 quotients on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each, as
 // K11's cell): the library expf / logf / IEEE division are 10-20 instructions each, ~200 of a step's 5 000 at the lone-wave issue rate
 __device__ __forceinline__ float bw_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504f * x); }
@@ -146,6 +153,8 @@ struct TrArgs {
     const float* h0;          // [E][P][H]  initial particles
     const float* eps;         // [L][E][P][H]
     const double* u;          // [L][E][P]  resampling uniforms; NULL: idx[] holds the indices to take (recorded draws)
+    const int64_t* keys;      // [E] or NULL.  Given (rs_pfgru_train_keyed): h0 / eps / u are NOT read -- the forward walk evaluates the counter hash
+                              // of rs_pfgru_draws itself (same keys, same arithmetic, bit-identical values; csrc/rs_pfgru.hip: rs_pfgru_draws_kernel)
     float* hs;                // [L][E][H / 4][P] float4 scratch: resampled particles after every step, quad-major
     float* ps;                // [L][E][P]    scratch: their log weights
     float* gates;             // [L][E][4 H / 4][P] float4 scratch: z | r | n | eps * softplus'(var) of the forward walk, QUAD-major (quad j of all 40
@@ -323,6 +332,9 @@ __device__ __forceinline__ float fw_sum40(const float* v) {          // index or
     return s;
 }
 
+// KEYED: the pass's draws (initial particles, reparameterisation noise, resampling uniforms) are hashed here instead of read: the draws
+// launch wrote 8.2 GB per pass at 16.5 k episodes (2.3 ms) for this kernel to read back -- K11 has always hashed in the kernel
+template <bool KEYED>
 __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(TrArgs a_) {
     __shared__ __align__(16) float smem[FW_SETS * FW_STRIDE];
     __shared__ int lens_s[FW_SETS];
@@ -357,7 +369,20 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
         }
     };
     float h0[H];
-    load24(a_.h0 + ((size_t)e * P + q) * H, h0);
+    uint64_t kb = 0;
+    if constexpr (KEYED) {
+        kb = (uint64_t)a_.keys[e] * 1000003ull;
+        const uint64_t k0 = kb * 1048583ull + (uint64_t)q * 4096ull;                      // kind 0, step 0
+#pragma unroll
+        for (int u = 0; u < H; ++u) h0[u] = (float)((double)(tr_hash(k0 + (uint64_t)u) >> 11) * (1.0 / 9007199254740992.0));
+        if (has) {                                                    // the backward walk's last step reads the initial particles
+            float4* dst = reinterpret_cast<float4*>(const_cast<float*>(a_.h0) + ((size_t)e * P + q) * H);
+#pragma unroll
+            for (int u = 0; u < H; u += 4) dst[u / 4] = make_float4(h0[u], h0[u + 1], h0[u + 2], h0[u + 3]);
+        }
+    } else {
+        load24(a_.h0 + ((size_t)e * P + q) * H, h0);
+    }
     float p0 = -3.6888794541139363f;                                 // float32(log(1 / 40))
     for (int t = 0; t < lmax; ++t) {
         const bool on = t < len;                                      // this episode is still running (uniform over its 40 lanes)
@@ -370,7 +395,20 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
 #pragma unroll
             for (int k = 0; k < IN; ++k) x[k] = o[k];
         }
-        load24(a_.eps + te * PH + (size_t)q * H, eps);
+        if constexpr (KEYED) {
+            const uint64_t k1 = (kb ^ ((uint64_t)(tc * 8 + 1) * 0xA24BAED4963EE407ull)) * 1048583ull + (uint64_t)q * 4096ull;
+#pragma unroll
+            for (int u = 0; u < H; u += 2) {                          // one hash per pair of units: Box-Muller's cosine and sine
+                const uint64_t hx = tr_hash(k1 + (uint64_t)u);
+                const float u1 = (float)((uint32_t)(hx >> 40) + 1u) * (1.0f / 16777216.0f);
+                const float u2 = (float)((uint32_t)(hx >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                const float r = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));
+                eps[u] = r * __builtin_amdgcn_cosf(u2);
+                eps[u + 1] = r * __builtin_amdgcn_sinf(u2);
+            }
+        } else {
+            load24(a_.eps + te * PH + (size_t)q * H, eps);
+        }
         pf_cell(W, h0, x, eps, reinterpret_cast<float4*>(a_.gates + te * (size_t)(P * 4 * H)) + q, on, h1, lg);
         K13_STAMP(0)                                                 // forward: loads + cell
         lg += p0;
@@ -389,7 +427,7 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
         }
         __syncthreads();                                             // 3
         int idx = 0;
-        if (a_.u) {
+        if (KEYED || a_.u) {
             double run = 0.0, mine = 0.0;                            // float64 prefix sums in index order
 #pragma unroll
             for (int i = 0; i < P / 4; ++i) {
@@ -401,7 +439,13 @@ __global__ void __launch_bounds__(FW_NT, K13_FW_OCC) rs_pfgru_train_fwd_kernel(T
             }
             if (act) cdf[q] = mine / run;
             __syncthreads();                                         // 4 (a_.u is a launch argument: every lane takes this branch or none)
-            const double ru = a_.u[te * P + q];
+            double ru;
+            if constexpr (KEYED) {
+                const uint64_t k2 = (kb ^ ((uint64_t)(tc * 8 + 2) * 0xA24BAED4963EE407ull)) * 1048583ull + (uint64_t)q * 4096ull;
+                ru = (double)(tr_hash(k2) >> 11) * (1.0 / 9007199254740992.0);
+            } else {
+                ru = a_.u[te * P + q];
+            }
 #pragma unroll
             for (int j = 0; j < P / 2; ++j) {                        // searchsorted(..., right=True)
                 const double2 c2 = reinterpret_cast<const double2*>(cdf)[j];
@@ -547,7 +591,7 @@ __global__ void __launch_bounds__(64) rs_pfgru_train_kernel(TrArgs a_) {
                 load24q(a_.hs + (te - E) * PH, h0);
                 p0 = a_.ps[(te - E) * P + pl];
             } else {
-                load24(a_.h0 + ((size_t)e * P + pl) * H, h0);
+                load24(a_.h0 + ((size_t)e * P + pl) * H, h0);      // (a keyed pass: written by the forward walk)
                 p0 = -3.6888794541139363f;
             }
             load_x(t, x);
@@ -823,6 +867,13 @@ int rs_debug_k13_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+static int pfgru_train_launch(const TrArgs& a, int32_t episodes, rs_stream_t stream) {
+    if (a.keys) hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel<true>, dim3((unsigned)((episodes + FW_SETS - 1) / FW_SETS)), dim3(FW_NT), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel<false>, dim3((unsigned)((episodes + FW_SETS - 1) / FW_SETS)), dim3(FW_NT), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+}
+
 int rs_pfgru_train(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
                    const float* h0, const float* eps, const double* u, float* hs, float* ps, float* gates, int32_t* idx, float* loss,
                    float* grads, int32_t steps, int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight,
@@ -830,11 +881,20 @@ int rs_pfgru_train(const float* weights, const float* obs, const float* target, 
     if (!weights || !obs || !target || !bp || !lens || !w_ep || !h0 || !eps || !hs || !ps || !gates || !idx || !loss || !grads || steps < 1 ||
         episodes < 1)
         return RS_ERR_INVALID_ARG;
-    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
+    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, eps, u, nullptr, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
              (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
-    hipLaunchKernelGGL(rs_pfgru_train_fwd_kernel, dim3((unsigned)((episodes + FW_SETS - 1) / FW_SETS)), dim3(FW_NT), 0, static_cast<hipStream_t>(stream), a);
-    hipLaunchKernelGGL(rs_pfgru_train_kernel, dim3((unsigned)episodes), dim3(64), 0, static_cast<hipStream_t>(stream), a);
-    return hipGetLastError() == hipSuccess ? RS_OK : RS_ERR_HIP;
+    return pfgru_train_launch(a, episodes, stream);
+}
+
+int rs_pfgru_train_keyed(const float* weights, const float* obs, const float* target, const float* bp, const int64_t* lens, const float* w_ep,
+                         const int64_t* keys, float* h0, float* hs, float* ps, float* gates, int32_t* idx, float* loss, float* grads, int32_t steps,
+                         int32_t episodes, double alpha, double l2_weight, double l1_weight, double elbo_weight, rs_stream_t stream) {
+    if (!weights || !obs || !target || !bp || !lens || !w_ep || !keys || !h0 || !hs || !ps || !gates || !idx || !loss || !grads || steps < 1 ||
+        episodes < 1)
+        return RS_ERR_INVALID_ARG;
+    TrArgs a{weights, obs, target, bp, lens, w_ep, h0, nullptr, nullptr, keys, hs, ps, gates, idx, loss, grads, steps, episodes, (float)alpha,
+             (float)((1.0 - alpha) / (double)P), (float)l2_weight, (float)l1_weight, (float)elbo_weight};
+    return pfgru_train_launch(a, episodes, stream);
 }
 
 }  // extern "C"

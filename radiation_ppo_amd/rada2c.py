@@ -320,6 +320,18 @@ class KernelDraws:
         return dict(resample_u=self._u[t])
 
 
+class KeyDraws:
+    """The draws of KernelDraws WITHOUT the buffers: K13's forward walk evaluates the counter hash itself (rs_pfgru_train_keyed; same keys,
+    same arithmetic, bit-identical values), as K11 always has.  The draws launch wrote 104 bytes per particle-step for the walk to read
+    back -- 8.2 GB and 2.3 ms per pass at 16.5 k episodes, 15 passes per update.  materialise(L): the buffers after all (tests)."""
+
+    def __init__(self, keys: torch.Tensor):
+        self.k = keys.contiguous()
+
+    def materialise(self, L: int) -> "KernelDraws":
+        return KernelDraws(self.k, L)
+
+
 class RecordedDraws:
     """The reference's own draws (tests): pf_h0 [E, P, H], gru_h0 [E, hid], eps [L, E, P, H], idx [L, E, P]."""
 
@@ -707,6 +719,16 @@ class RNNAgentPPO:
         w = pack_train_weights(self.agent.model)
         # for the bench's roofline entry: one count per launch of the current update_model, in launch order (as _lib.EVENTS["rs_pfgru_train"])
         self.k13_particle_steps.append(particle_steps)
+        if isinstance(d, KeyDraws):
+            idx.zero_()
+            h0s = sc.get("k13_h0", (E, 40, 24), torch.float32, dev)
+            with _lib.timed("rs_pfgru_train"):
+                _lib.check(_lib.load().rs_pfgru_train_keyed(w.data_ptr(), X.data_ptr(), tar.data_ptr(), bp.data_ptr(), lens.data_ptr(), w_ep.data_ptr(),
+                                                            d.k.data_ptr(), h0s.data_ptr(), hs.data_ptr(), ps.data_ptr(), gates.data_ptr(), idx.data_ptr(), loss.data_ptr(),
+                                                            slab.data_ptr(), L, E, float(self.agent.model.resamp_alpha), float(a.l2_weight),
+                                                            float(a.l1_weight), float(a.elbo_weight),
+                                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train_keyed")
+            return loss.double().sum(), slab.sum(dim=0), idx
         if d._u is None:                                                           # recorded draws: idx is the kernel's INPUT
             idx.copy_(d._idx32)
         else:
@@ -719,9 +741,9 @@ class RNNAgentPPO:
                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rs_pfgru_train")
         return loss.double().sum(), slab.sum(dim=0), idx
 
-    # K13's scratch per episode of L steps, bytes: gates 40 x 96, particle sets + noise 2 x 40 x 24 floats, resampling uniforms 40 doubles,
-    # log weights + indices 2 x 40 words per step (+ Scratch's 1/8 headroom)
-    _K13_BYTES_PER_EPISODE_STEP = (40 * 96 + 2 * 40 * 24) * 4 + 40 * 8 + 2 * 40 * 4
+    # K13's scratch per episode of L steps, bytes: gates 40 x 96, particle sets 40 x 24 floats, log weights + indices 2 x 40 words per step
+    # (+ Scratch's 1/8 headroom); the noise and the resampling uniforms are hashed in the kernel (KeyDraws)
+    _K13_BYTES_PER_EPISODE_STEP = (40 * 96 + 40 * 24) * 4 + 2 * 40 * 4
 
     def _k13_chunk(self, L: int, E: int) -> int:
         """Episodes per K13 pass: `episode_chunk`, clamped so that the pass's scratch fits the memory that is free NOW (plus what the
@@ -756,11 +778,13 @@ class RNNAgentPPO:
                 sl = slice(lo, min(lo + chunk, E))
                 if draws_for is not None:
                     d = draws_for(it, sl)
+                elif self.device.type == "cuda" and self.agent.fused_pfgru and getattr(self, "use_k13", True):
+                    d = KeyDraws(B.key[sl] * 64 + 1 + it)                           # hashed inside K13's forward walk
                 elif self.device.type == "cuda" and self.agent.fused_pfgru:
                     d = KernelDraws(B.key[sl] * 64 + 1 + it, B.chunk(sl).X.shape[0], scratch=self.scratch)
                 else:
                     d = HashDraws(B.key[sl] * 64 + 1 + it, H=self.agent.rec, hid=self.agent.hid)
-                if isinstance(d, (KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
+                if isinstance(d, (KeyDraws, KernelDraws, RecordedKernelDraws)) and getattr(self, "use_k13", True):
                     # K13: the episode loop, the loss and its back-propagation through time in one call (two launches)
                     loss, g, _ = self.model_pass_hip(B, sl, d)
                     by_name = unpack_train_grads(cell, g)

@@ -60,7 +60,8 @@ def _find(kernels, *parts):
     (("rs_pfgru_kernelILb0ELi1E",), 168),            # K11 collector step: three waves per SIMD (512 / 3, granule 8)
     (("rs_pfgru_kernelILb0ELi4E",), 168),            # K11 pass (four steps per launch)
     (("rs_pfgru_kernelILb1ELi1E",), 168),            # K11 with recorded draws
-    (("rs_pfgru_train_fwd_kernel",), 256),           # K13 forward walk: two waves per SIMD
+    (("rs_pfgru_train_fwd_kernelILb1E",), 256),      # K13 forward walk (draws hashed in the kernel): two waves per SIMD
+    (("rs_pfgru_train_fwd_kernelILb0E",), 256),      # K13 forward walk (draws read)
     (("rs_pfgru_train_kernel",), 512),               # K13 backward walk: one wave per SIMD
     (("rs_cnn_fwd_kernelILi6E",), 128),              # K9: four waves per SIMD
     (("rs_cnn_fwd_kernelILi4E",), 128),
@@ -81,4 +82,4 @@ def test_lds_budgets(kernels):
     cu = 160 * 1024
     assert cu // _find(kernels, "rs_pfgru_train_kernel")["lds"] == 4
     assert cu // _find(kernels, "rs_pfgru_kernelILb0ELi4E")["lds"] >= 3
-    assert cu // _find(kernels, "rs_pfgru_train_fwd_kernel")["lds"] >= 2
+    assert cu // _find(kernels, "rs_pfgru_train_fwd_kernelILb1E")["lds"] >= 2

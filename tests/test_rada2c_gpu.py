@@ -293,6 +293,33 @@ def test_pfgru_training_kernel_matches_autograd(l1):
         assert same >= tot - 2, (same, tot)
 
 
+def test_pfgru_training_kernel_with_hashed_draws_is_bit_identical():
+    """rs_pfgru_train_keyed (the forward walk evaluates the counter hash itself: KeyDraws) against rs_pfgru_train fed the buffers
+    rs_pfgru_draws wrote for the same keys: same loss, same gradient slabs, same resampling indices, bit for bit -- ragged episodes,
+    a one-step episode, more episodes than one workgroup holds."""
+    from radiation_ppo_amd.rada2c import BpArgs, KeyDraws, RNNAgentPPO, pack_episodes
+    g = torch.Generator().manual_seed(11)
+    T, N = 48, 40
+    obs = torch.rand(T, N, 11, generator=g).cuda()
+    act = torch.randint(0, 8, (T, N), generator=g).cuda()
+    z = torch.zeros(T, N).cuda()
+    src = (torch.rand(T, N, 2, generator=g) * 2000 + 200).cuda()
+    cut = (torch.rand(T, N, generator=g) < 0.06).to(torch.uint8)
+    cut[-1] = 1
+    cut[0, 5] = 1
+    B = pack_episodes(obs, act, z, z, z, src, cut.cuda(), n_total=N, seed=7, sort_by_length=True)
+    E = B.lens.shape[0]
+    ag = RNNAgentPPO(id=0, seed=3, bp_args=BpArgs(l1_weight=0.5, area_scale=2500.0))
+    sl = slice(0, E)
+    kd = KeyDraws(B.key * 64 + 1 + 4)
+    loss_a, slab_a, idx_a = ag.model_pass_hip(B, sl, kd)
+    slab_a, idx_a = slab_a.clone(), idx_a.clone()
+    loss_b, slab_b, idx_b = ag.model_pass_hip(B, sl, kd.materialise(B.X.shape[0]))
+    assert float(loss_a) == float(loss_b)
+    assert torch.equal(idx_a, idx_b)
+    assert torch.equal(slab_a, slab_b)
+
+
 def _pre_resample(cell, X3, h0, p0, eps):
     keep = cell.use_resampling
     cell.use_resampling = False
