@@ -68,10 +68,12 @@ if driver_log and os.path.exists(driver_log):
         alg = info["algorithmic_bytes_per_launch"]
         # one K13 pass = the forward walk + the backward walk (two launches since round 3): their traffic is reported together under the
         # backward kernel's name, which is what bench.py's roofline entry looks up
-        if "rs_pfgru_train_fwd_kernel" in lg and "rs_pfgru_train_kernel" in lg:
+        fwd = [k for k in lg if k.startswith("rs_pfgru_train_fwd_kernel")]          # <true>: the draws hashed in the walk (the product path)
+        if fwd and "rs_pfgru_train_kernel" in lg:
+            fk = "rs_pfgru_train_fwd_kernel<true>" if "rs_pfgru_train_fwd_kernel<true>" in lg else fwd[0]
             lg["rs_pfgru_train_kernel"] = {"grid": lg["rs_pfgru_train_kernel"]["grid"],
                                            "hbm_bytes_per_launch": lg["rs_pfgru_train_kernel"]["hbm_bytes_per_launch"]
-                                           + lg["rs_pfgru_train_fwd_kernel"]["hbm_bytes_per_launch"], "note": "forward + backward walk"}
+                                           + lg[fk]["hbm_bytes_per_launch"], "note": "forward (" + fk + ") + backward walk"}
         res["per_unit"] = {}
         for k, (unit, n) in units.items():
             if k in lg:

@@ -104,7 +104,7 @@ col.collect()
 col.update()
 torch.cuda.synchronize()
 ps = ag[0].k13_particle_steps[-1]                  # (one chunk: every K13 launch of the update covers the whole epoch)
-# per particle-step: forward reads eps 96 B, writes the resampled particle 96 + 4 + 4 B and the gates 384 B; backward reads the gates 384 B,
-# two particle sets 200 B and the index 4 B
-alg["rs_pfgru_train_kernel"] = ps * (96 + 104 + 384 + 384 + 2 * 100 + 4)
+# per particle-step: forward writes the resampled particle 96 + 4 + 4 B and the gates 384 B (the draws are hashed in the walk since the end of
+# round 4: no 96 + 8 B of noise / uniform to read); backward reads the gates 384 B, two particle sets 200 B and the index 4 B
+alg["rs_pfgru_train_kernel"] = ps * (104 + 384 + 384 + 2 * 100 + 4)
 print(json.dumps({"algorithmic_bytes_per_launch": alg, "k13_particle_steps": ps}))
