@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from radiation_ppo_amd.rada2c import KernelDraws, RNNAgentPPO, pack_episodes  # noqa: E402
+from radiation_ppo_amd.rada2c import KeyDraws, RNNAgentPPO, pack_episodes  # noqa: E402
 
 g = torch.Generator().manual_seed(4)
 T, N = 120, int(os.environ.get("K13_EPISODES", "8192"))
@@ -19,7 +19,7 @@ cut = torch.zeros(T, N, dtype=torch.uint8); cut[-1] = 1
 B = pack_episodes(obs, act, z, z, z, src, cut.cuda(), n_total=N, seed=3)
 ag = RNNAgentPPO(id=0, seed=1)
 sl = slice(0, B.lens.shape[0])
-kd = KernelDraws(B.key * 64 + 1, B.X.shape[0])
+kd = KeyDraws(B.key * 64 + 1)                         # the product path: draws hashed in the forward walk
 ag.model_pass_hip(B, sl, kd); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
